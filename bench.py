@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: 1-D c2c fp32 forward FFT, N = 2^20, batch = 4096 per GPU.
+
+One step = one `Forward.proc` over the whole per-GPU batch (synthetic interleaved complex fp32,
+generated on the device, resident in HBM before the clock starts).  One process per GPU; batches
+shard as independent slabs (no data-path collective), so scaling is "weak": every rank runs the
+full 4096-transform slab (config C4 = 4096 per GPU x 8).
+
+Timing: K steps inside barrier + torch.cuda.synchronize() brackets, wall clock, MAX over ranks.
+Because a forward FFT multiplies the RMS by 2^10 and `proc` works in place, the K steps run in
+chunks of <= 8 with the input regenerated (at scale 2^-40) between chunks, outside the brackets,
+so fp32 never overflows to inf/NaN (benchmarks on degenerate data are not representative).
+HIP events on the launch stream time each step for the roofline object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_SAMPLE = 16      # one 8-B read + one 8-B write per complex sample
+CHUNK = 8                       # steps between input regenerations (2^-40 * 2^(10*8) stays finite)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--fft-len", type=int, default=1 << 20)
+    ap.add_argument("--batch", type=int, default=4096, help="transforms per GPU")
+    ap.add_argument("--group", type=int, default=0, help="override plan tunable (0 = default)")
+    ap.add_argument("--streams", type=int, default=0, help="override plan tunable (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fft_wgpu_amd as fw
+
+    got = fw.prepare_gpu(local_rank)
+    if got is None:
+        raise SystemExit("no usable gfx950 device")
+    dev, queue = got
+    n, batch = args.fft_len, args.batch
+    nbytes = n * batch * fw.COMPLEX_BYTES
+    buf = dev.create_buffer(nbytes)
+    plan = fw.Forward(dev, queue, buf, n)
+    if args.group:
+        plan.set("group", args.group)
+    if args.streams:
+        plan.set("streams", args.streams)
+    enc = dev.create_command_encoder()   # the stream every kernel of the timed region is launched on
+    first = rank * batch                 # this rank's slab of the global batch (sharding.slab with equal slabs)
+
+    def regen():
+        dev.fill_synthetic(buf, n, first_transform=first, scale=2.0 ** -40, encoder=enc)
+        enc.synchronize()
+
+    def barrier():
+        enc.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    regen()
+    for _ in range(args.warmup):
+        plan.proc(enc)
+    barrier()
+
+    ev = [(fw.Event(dev), fw.Event(dev)) for _ in range(args.steps)]
+    wall = 0.0
+    done = 0
+    while done < args.steps:
+        k = min(CHUNK, args.steps - done)
+        regen()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            ev[done + i][0].record(enc)
+            plan.proc(enc)
+            ev[done + i][1].record(enc)
+        barrier()
+        wall += time.perf_counter() - t0
+        done += k
+    step_ms_events = [a.elapsed_ms(b) for a, b in ev]
+
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    # calibration: float4 copy of 8 GiB (read + write) on the same stream, same run
+    copy_gbps = None
+    if rank == 0:
+        half = min(nbytes // 2, 8 << 30) // 16 * 16
+        if half >= (1 << 20):
+            src_view = dev.wrap_buffer(buf.device_ptr, half)
+            dst_view = dev.wrap_buffer(buf.device_ptr + half, half)
+            dev.calib_copy(dst_view, src_view, half, encoder=enc)
+            a, b = fw.Event(dev), fw.Event(dev)
+            a.record(enc)
+            for _ in range(3):
+                dev.calib_copy(dst_view, src_view, half, encoder=enc)
+            b.record(enc)
+            copy_gbps = 3 * 2 * half / (a.elapsed_ms(b) * 1e-3) / 1e9
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
+        cores = len(os.sched_getaffinity(0))
+        cb = max(cores, 8)
+        sps, reps = oracle.bench_forward(n, cb, threads=cores, min_seconds=args.cpu_seconds)
+        cpu = {"value": sps / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": "port",
+               "sample": f"{cb} transforms of N={n} (same generator, seed 0x5EED), best of {reps} repetitions, "
+                         f"OpenMP over transforms; CPU restatement of the reference radix-2 Stockham algorithm"}
+
+    if rank == 0:
+        samples_per_step = n * batch * world
+        ms_per_step = wall_max / args.steps * 1e3
+        value = samples_per_step / (wall_max / args.steps) / 1e9
+        ev_ms = sum(step_ms_events) / len(step_ms_events)
+        achieved = ALGO_BYTES_PER_SAMPLE * n * batch / (ev_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{n}x{batch}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gsamples/s, 1-D c2c fp32 forward FFT N=2^20 batch=4096 per GPU",
+            "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1-D c2c fp32 FFT N={n} batch={batch} per GPU (BASELINE.json configs[2]"
+                                   f"{'; configs[3] shape' if world > 1 else ''})",
+                       "fft_len": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective",
+                       "plan_path": plan.get("path"), "group": plan.get("group"), "streams": plan.get("streams"),
+                       "launches_per_step": plan.get("launches_per_exec"),
+                       "scratch_bytes": plan.get("scratch_bytes")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "fwa_plan_exec (k_p1_1m + k_p2_1m pipeline)",
+                         "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),
+                         "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
+                         "copy_ceiling_GBps_same_run": copy_gbps},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""ctypes binding of include/fft_wgpu_amd.h (the C-ABI drop-in boundary).
+
+There is no fallback: if the HIP library is missing or a call fails, this
+module raises.  Nothing here imports ``oracle``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfft_wgpu_amd.so")
+
+FWA_OK = 0
+FORWARD, INVERSE_SCALED, INVERSE_UNSCALED, NORMALIZE = 0, 1, 2, 3
+STATUS_NAMES = {
+    0: "FWA_OK", 1: "FWA_ERR_INVALID_ARG", 2: "FWA_ERR_OUT_OF_MEMORY", 3: "FWA_ERR_HIP",
+    4: "FWA_ERR_LAUNCH", 5: "FWA_ERR_NO_DEVICE", 6: "FWA_ERR_UNSUPPORTED",
+}
+
+
+class FwaError(RuntimeError):
+    def __init__(self, status, detail, where):
+        self.status = status
+        self.detail = detail
+        super().__init__(f"{where}: {STATUS_NAMES.get(status, status)}: {detail}")
+
+
+_P = ctypes.c_void_p
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_U64 = ctypes.c_uint64
+_U32 = ctypes.c_uint32
+_I32 = ctypes.c_int32
+
+_SIGNATURES = {
+    "fwa_abi_version": (_I32, []),
+    "fwa_last_error_string": (ctypes.c_char_p, [_P]),
+    "fwa_status_string": (ctypes.c_char_p, [_I32]),
+    "fwa_device_count": (_I32, [ctypes.POINTER(_I32)]),
+    "fwa_ctx_create": (_I32, [_I32, _PP]),
+    "fwa_ctx_destroy": (_I32, [_P]),
+    "fwa_ctx_device_info": (_I32, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_I32),
+                                   ctypes.POINTER(_U64)]),
+    "fwa_stream_create": (_I32, [_P, _PP]),
+    "fwa_stream_wrap": (_I32, [_P, _P, _PP]),
+    "fwa_stream_synchronize": (_I32, [_P]),
+    "fwa_stream_destroy": (_I32, [_P]),
+    "fwa_buf_alloc": (_I32, [_P, _U64, _PP]),
+    "fwa_buf_wrap": (_I32, [_P, _P, _U64, _PP]),
+    "fwa_buf_free": (_I32, [_P]),
+    "fwa_buf_upload": (_I32, [_P, _U64, _P, _U64, _P]),
+    "fwa_buf_download": (_I32, [_P, _P, _U64, _U64, _P]),
+    "fwa_buf_copy": (_I32, [_P, _U64, _P, _U64, _U64, _P]),
+    "fwa_buf_device_ptr": (_P, [_P]),
+    "fwa_buf_size": (_U64, [_P]),
+    "fwa_plan_create": (_I32, [_P, _I32, _U32, _P, _P, _PP]),
+    "fwa_plan_exec": (_I32, [_P, _P, _PP]),
+    "fwa_plan_destroy": (_I32, [_P]),
+    "fwa_plan_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "fwa_plan_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
+    "fwa_event_create": (_I32, [_P, _PP]),
+    "fwa_event_record": (_I32, [_P, _P]),
+    "fwa_event_elapsed_ms": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
+    "fwa_event_destroy": (_I32, [_P]),
+    "fwa_fill_synthetic": (_I32, [_P, _U64, _U64, _U32, ctypes.c_float, _P]),
+    "fwa_calib_copy": (_I32, [_P, _P, _U64, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it was not built: no CPU fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fft_wgpu_amd/csrc`.  fft_wgpu_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, ctx_handle, where):
+    if status != FWA_OK:
+        msg = lib().fwa_last_error_string(ctx_handle)
+        raise FwaError(status, msg.decode() if msg else "", where)

@@ -1,0 +1,678 @@
+// api.cpp -- host side of the C ABI declared in include/fft_wgpu_amd.h.
+//
+// Mirrors the plan objects of reference src/processor.rs (Forward :7-159,
+// Inverse :231-341, Normalize :409-505, Onlyinverse :566-670) without any of
+// its wgpu plumbing: a plan owns its twiddle tables and scratch, exec only
+// enqueues kernels on the caller's stream and allocates nothing.
+#include "../../include/fft_wgpu_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using fwa::v2f;
+
+struct fwa_ctx {
+    int device = -1;
+    hipDeviceProp_t prop{};
+    mutable std::string err;
+    bool setup_1m_done = false;
+};
+struct fwa_stream {
+    fwa_ctx *ctx = nullptr;
+    hipStream_t s = nullptr;
+    bool owned = false;
+};
+struct fwa_buf {
+    fwa_ctx *ctx = nullptr;
+    void *p = nullptr;
+    uint64_t bytes = 0;
+    bool owned = false;
+};
+struct fwa_event {
+    fwa_ctx *ctx = nullptr;
+    hipEvent_t e = nullptr;
+};
+
+enum fwa_path : int64_t {
+    PATH_LDS_SMALL = 0,
+    PATH_TWOPASS_1M = 1,
+    PATH_R2_GLOBAL = 2,
+    PATH_NORMALIZE = 3,
+    PATH_IDENTITY = 4,
+};
+
+struct fwa_plan {
+    fwa_ctx *ctx = nullptr;
+    int32_t kind = 0;
+    uint32_t n = 0;
+    uint32_t lg = 0;
+    uint64_t batch = 0;
+    fwa_buf *src = nullptr;        // buffer_a (processor.rs:12,237,575) / buffer1 for Normalize
+    fwa_buf *second = nullptr;     // buffer_b: plan-owned (Forward/Inverse) or caller's src2
+    fwa_buf own_second;            // storage when plan-owned
+    bool second_owned = false;
+    int64_t path = PATH_R2_GLOBAL;
+    bool frozen = false;           // first exec done -> tunables locked
+    // tables (device)
+    v2f *tw_half = nullptr;        // n/2 entries, processor.rs:43-49
+    v2f *tw_inner = nullptr;       // 2^20 path: [k1][n'] = W_1024^{n' k1}
+    v2f *tw_outer = nullptr;       // 2^20 path: per tile A[32][16], B[32][16]
+    // 2^20 pipeline
+    v2f *ring = nullptr;
+    int64_t group = 8;             // transforms per launch pair
+    int64_t n_streams = 2;         // internal streams the groups alternate over
+    uint64_t ring_slots = 0;
+    std::vector<hipStream_t> istreams;
+    std::vector<hipEvent_t> idone;
+    hipEvent_t ev_fork = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;  // ctx-less failures
+
+int32_t fail(const fwa_ctx *ctx, int32_t st, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    else g_err = msg;
+    return st;
+}
+int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t st = FWA_ERR_HIP)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    if (e == hipErrorOutOfMemory) st = FWA_ERR_OUT_OF_MEMORY;
+    return fail(ctx, st, m);
+}
+
+#define HIP_TRY(ctx, call)                                       \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #call); \
+    } while (0)
+
+bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
+uint32_t ilog2(uint32_t n)
+{
+    uint32_t l = 0;
+    while ((1u << l) < n) ++l;
+    return l;
+}
+
+// reference twiddle rule, processor.rs:43-49: f64 math, rounded to f32.
+v2f tw_f64(uint64_t k, uint64_t n)
+{
+    const double PI = 3.14159265358979323846;
+    const double theta = -2.0 * PI * (double)k / (double)n;
+    return v2f{(float)std::cos(theta), (float)std::sin(theta)};
+}
+
+int32_t upload_table(fwa_ctx *ctx, const std::vector<v2f> &h, v2f **d)
+{
+    *d = nullptr;
+    if (h.empty()) return FWA_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(d), h.size() * sizeof(v2f)));
+    HIP_TRY(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    return FWA_OK;
+}
+
+hipStream_t raw(fwa_stream *s) { return s ? s->s : nullptr; }
+
+void release_pipeline(fwa_plan *p)
+{
+    for (auto s : p->istreams) (void)hipStreamDestroy(s);
+    for (auto e : p->idone) (void)hipEventDestroy(e);
+    p->istreams.clear();
+    p->idone.clear();
+    if (p->ev_fork) { (void)hipEventDestroy(p->ev_fork); p->ev_fork = nullptr; }
+    if (p->ring) { (void)hipFree(p->ring); p->ring = nullptr; }
+}
+
+// Allocate the scratch ring and the internal streams of the 2^20 pipeline (first exec or plan creation).
+int32_t build_pipeline(fwa_plan *p)
+{
+    fwa_ctx *ctx = p->ctx;
+    release_pipeline(p);
+    if (p->group < 1) p->group = 1;
+    if ((uint64_t)p->group > p->batch && p->batch) p->group = (int64_t)p->batch;
+    const uint64_t n_groups = p->batch ? (p->batch + p->group - 1) / p->group : 0;
+    if (p->n_streams < 1) p->n_streams = 1;
+    if ((uint64_t)p->n_streams > n_groups && n_groups) p->n_streams = (int64_t)n_groups;
+    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams;
+    if (p->ring_slots == 0) return FWA_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->ring), p->ring_slots * (sizeof(v2f) << 20)));
+    if (p->n_streams > 1) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        for (int64_t i = 0; i < p->n_streams; ++i) {
+            hipStream_t s;
+            hipEvent_t e;
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            p->istreams.push_back(s);
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            p->idone.push_back(e);
+        }
+    }
+    return FWA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t fwa_abi_version(void) { return FWA_ABI_VERSION; }
+
+const char *fwa_last_error_string(const fwa_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+const char *fwa_status_string(int32_t status)
+{
+    switch (status) {
+        case FWA_OK: return "ok";
+        case FWA_ERR_INVALID_ARG: return "invalid argument";
+        case FWA_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case FWA_ERR_HIP: return "HIP runtime error";
+        case FWA_ERR_LAUNCH: return "kernel launch failed";
+        case FWA_ERR_NO_DEVICE: return "no usable device";
+        case FWA_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+int32_t fwa_device_count(int32_t *count)
+{
+    if (!count) return fail(nullptr, FWA_ERR_INVALID_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(nullptr, e, "hipGetDeviceCount", FWA_ERR_NO_DEVICE);
+    }
+    *count = n;
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out)
+{
+    if (!out) return fail(nullptr, FWA_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, FWA_ERR_NO_DEVICE,
+                    std::string("no HIP device visible: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, FWA_ERR_INVALID_ARG, "device ordinal out of range");
+    fwa_ctx *ctx = new (std::nothrow) fwa_ctx;
+    if (!ctx) return fail(nullptr, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device_ordinal;
+    e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
+    if (e != hipSuccess) {
+        int32_t st = fail_hip(nullptr, e, "hipSetDevice/hipGetDeviceProperties", FWA_ERR_NO_DEVICE);
+        delete ctx;
+        return st;
+    }
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        int32_t st = fail(nullptr, FWA_ERR_NO_DEVICE,
+                          std::string("device is ") + ctx->prop.gcnArchName + ", this library is built for gfx950 only");
+        delete ctx;
+        return st;
+    }
+    *out = ctx;
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_destroy(fwa_ctx *ctx)
+{
+    delete ctx;
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap, int32_t *compute_units,
+                            uint64_t *hbm_bytes)
+{
+    if (!ctx) return fail(nullptr, FWA_ERR_INVALID_ARG, "ctx is NULL");
+    if (name && name_cap) {
+        std::strncpy(name, ctx->prop.gcnArchName, name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return FWA_OK;
+}
+
+// ---- streams -------------------------------------------------------------
+int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
+{
+    if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    fwa_stream *st = new (std::nothrow) fwa_stream;
+    if (!st) { (void)hipStreamDestroy(s); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    st->ctx = ctx; st->s = s; st->owned = true;
+    *out = st;
+    return FWA_OK;
+}
+
+int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out)
+{
+    if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
+    fwa_stream *st = new (std::nothrow) fwa_stream;
+    if (!st) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    st->ctx = ctx; st->s = reinterpret_cast<hipStream_t>(hip_stream); st->owned = false;
+    *out = st;
+    return FWA_OK;
+}
+
+int32_t fwa_stream_synchronize(fwa_stream *stream)
+{
+    if (!stream) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    HIP_TRY(stream->ctx, hipStreamSynchronize(stream->s));
+    return FWA_OK;
+}
+
+int32_t fwa_stream_destroy(fwa_stream *stream)
+{
+    if (!stream) return FWA_OK;
+    if (stream->owned) (void)hipStreamDestroy(stream->s);
+    delete stream;
+    return FWA_OK;
+}
+
+// ---- buffers -------------------------------------------------------------
+int32_t fwa_buf_alloc(fwa_ctx *ctx, uint64_t bytes, fwa_buf **out)
+{
+    if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (bytes) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc");
+    }
+    fwa_buf *b = new (std::nothrow) fwa_buf;
+    if (!b) { (void)hipFree(p); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    b->ctx = ctx; b->p = p; b->bytes = bytes; b->owned = true;
+    *out = b;
+    return FWA_OK;
+}
+
+int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **out)
+{
+    if (!ctx || !out || (!device_ptr && bytes)) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out/device_ptr is NULL");
+    if (reinterpret_cast<uintptr_t>(device_ptr) & 15)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "device pointer must be 16-byte aligned");
+    fwa_buf *b = new (std::nothrow) fwa_buf;
+    if (!b) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    b->ctx = ctx; b->p = device_ptr; b->bytes = bytes; b->owned = false;
+    *out = b;
+    return FWA_OK;
+}
+
+int32_t fwa_buf_free(fwa_buf *buf)
+{
+    if (!buf) return FWA_OK;
+    if (buf->owned && buf->p) (void)hipFree(buf->p);
+    delete buf;
+    return FWA_OK;
+}
+
+int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint64_t bytes, fwa_stream *stream)
+{
+    if (!dst || (!host && bytes)) return fail(dst ? dst->ctx : nullptr, FWA_ERR_INVALID_ARG, "dst/host is NULL");
+    if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset)
+        return fail(dst->ctx, FWA_ERR_INVALID_ARG, "upload range exceeds buffer");
+    if (!bytes) return FWA_OK;
+    HIP_TRY(dst->ctx, hipMemcpyAsync(static_cast<char *>(dst->p) + dst_offset, host, bytes, hipMemcpyHostToDevice,
+                                     raw(stream)));
+    return FWA_OK;
+}
+
+int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes, fwa_stream *stream)
+{
+    if (!src || (!host && bytes)) return fail(src ? src->ctx : nullptr, FWA_ERR_INVALID_ARG, "src/host is NULL");
+    if (src_offset > src->bytes || bytes > src->bytes - src_offset)
+        return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
+    if (!bytes) return FWA_OK;
+    HIP_TRY(src->ctx, hipMemcpyAsync(host, static_cast<const char *>(src->p) + src_offset, bytes,
+                                     hipMemcpyDeviceToHost, raw(stream)));
+    // map_async + poll(wait) in the reference (examples/basic.rs:105-106): the data is on the host on return
+    HIP_TRY(src->ctx, hipStreamSynchronize(raw(stream)));
+    return FWA_OK;
+}
+
+int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint64_t src_offset, uint64_t bytes,
+                     fwa_stream *stream)
+{
+    if (!dst || !src) return fail(nullptr, FWA_ERR_INVALID_ARG, "dst/src is NULL");
+    if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset || src_offset > src->bytes ||
+        bytes > src->bytes - src_offset)
+        return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy range exceeds buffer");
+    if (!bytes) return FWA_OK;
+    HIP_TRY(dst->ctx, hipMemcpyAsync(static_cast<char *>(dst->p) + dst_offset,
+                                     static_cast<const char *>(src->p) + src_offset, bytes, hipMemcpyDeviceToDevice,
+                                     raw(stream)));
+    return FWA_OK;
+}
+
+void *fwa_buf_device_ptr(const fwa_buf *buf) { return buf ? buf->p : nullptr; }
+uint64_t fwa_buf_size(const fwa_buf *buf) { return buf ? buf->bytes : 0; }
+
+// ---- plans ----------------------------------------------------------------
+int32_t fwa_plan_destroy(fwa_plan *plan)
+{
+    if (!plan) return FWA_OK;
+    release_pipeline(plan);
+    if (plan->tw_half) (void)hipFree(plan->tw_half);
+    if (plan->tw_inner) (void)hipFree(plan->tw_inner);
+    if (plan->tw_outer) (void)hipFree(plan->tw_outer);
+    if (plan->second_owned && plan->own_second.p) (void)hipFree(plan->own_second.p);
+    delete plan;
+    return FWA_OK;
+}
+
+int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *src, fwa_buf *src2_or_null,
+                        fwa_plan **out)
+{
+    if (!out) return fail(ctx, FWA_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !src) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/src is NULL");
+    if (kind < FWA_FORWARD || kind > FWA_NORMALIZE) return fail(ctx, FWA_ERR_INVALID_ARG, "unknown plan kind");
+    if (!is_pow2(fft_len)) return fail(ctx, FWA_ERR_INVALID_ARG, "fft_len must be a power of two >= 1");
+    if (fft_len > (1u << 30)) return fail(ctx, FWA_ERR_UNSUPPORTED, "fft_len above 2^30 is not supported");
+    const uint64_t tbytes = (uint64_t)fft_len * 8;
+    if (src->bytes % tbytes != 0)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "buffer size is not a multiple of 8*fft_len bytes");
+    const bool needs_src2 = (kind == FWA_INVERSE_UNSCALED || kind == FWA_NORMALIZE);
+    if (needs_src2 && !src2_or_null)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "this plan kind needs a caller-supplied second buffer");
+    if (!needs_src2 && src2_or_null)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "this plan kind owns its second buffer; pass NULL");
+    if (src2_or_null && src2_or_null->bytes != src->bytes)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "second buffer must have the size of the first");
+    if (src2_or_null && src2_or_null->p == src->p && src->bytes)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "the two buffers must be distinct");
+    if (reinterpret_cast<uintptr_t>(src->p) & 15) return fail(ctx, FWA_ERR_INVALID_ARG, "buffer must be 16-byte aligned");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fwa_plan *p = new (std::nothrow) fwa_plan;
+    if (!p) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    p->ctx = ctx; p->kind = kind; p->n = fft_len; p->lg = ilog2(fft_len);
+    p->batch = src->bytes / tbytes;
+    p->src = src; p->second = src2_or_null;
+
+    int32_t st = FWA_OK;
+    auto bail = [&](int32_t s) { fwa_plan_destroy(p); return s; };
+
+    if (kind == FWA_NORMALIZE) {
+        p->path = PATH_NORMALIZE;
+        *out = p;
+        return FWA_OK;
+    }
+
+    if (fft_len == 1) p->path = PATH_IDENTITY;
+    else if (fft_len <= 4096) p->path = PATH_LDS_SMALL;
+    else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;
+    else p->path = PATH_R2_GLOBAL;
+
+    // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
+    // materialised when the result must land there (odd log2 n) or the path ping-pongs.
+    const bool odd = (p->lg & 1) != 0;
+    const bool need_second = odd || p->path == PATH_R2_GLOBAL;
+    if (!p->second && need_second && src->bytes) {
+        hipError_t e = hipMalloc(&p->own_second.p, src->bytes);
+        if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipMalloc(second buffer)"));
+        p->own_second.ctx = ctx; p->own_second.bytes = src->bytes; p->own_second.owned = false;
+        p->second = &p->own_second;
+        p->second_owned = true;
+    } else if (!p->second) {
+        // even log2 n on an in-place path: the reference would still own a buffer_b; we keep a
+        // zero-sized handle so the result rule never dereferences NULL.
+        p->own_second.ctx = ctx;
+        p->second = &p->own_second;
+    }
+
+    if (p->path == PATH_LDS_SMALL || p->path == PATH_R2_GLOBAL) {
+        std::vector<v2f> h(fft_len / 2);
+        for (uint32_t k = 0; k < fft_len / 2; ++k) h[k] = tw_f64(k, fft_len);
+        st = upload_table(ctx, h, &p->tw_half);
+        if (st) return bail(st);
+    } else if (p->path == PATH_TWOPASS_1M) {
+        if (!ctx->setup_1m_done) {
+            hipError_t e = fwa::setup_1m_kernels();
+            if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
+            ctx->setup_1m_done = true;
+        }
+        std::vector<v2f> inner(1024), outer((size_t)64 * 1024);
+        for (uint32_t k1 = 0; k1 < 32; ++k1)
+            for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
+        const uint64_t N = 1ull << 20;
+        for (uint32_t tile = 0; tile < 64; ++tile)
+            for (uint32_t k = 0; k < 32; ++k)
+                for (uint32_t c = 0; c < 16; ++c) {
+                    const uint64_t n2 = 16 * tile + c;
+                    outer[(size_t)tile * 1024 + k * 16 + c] = tw_f64(n2 * k, N);             // A[k1][c]
+                    outer[(size_t)tile * 1024 + 512 + k * 16 + c] = tw_f64(32 * n2 * k, N);  // B[k2][c]
+                }
+        st = upload_table(ctx, inner, &p->tw_inner);
+        if (st) return bail(st);
+        st = upload_table(ctx, outer, &p->tw_outer);
+        if (st) return bail(st);
+        st = build_pipeline(p);
+        if (st) return bail(st);
+    }
+    *out = p;
+    return FWA_OK;
+}
+
+static fwa_buf *result_buffer(fwa_plan *p)
+{
+    // processor.rs:153-157, :335-339, :664-668
+    return (p->lg % 2 == 0) ? p->src : p->second;
+}
+
+int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
+{
+    if (!plan) return fail(nullptr, FWA_ERR_INVALID_ARG, "plan is NULL");
+    fwa_ctx *ctx = plan->ctx;
+    hipStream_t st = raw(stream);
+    plan->frozen = true;
+    const uint64_t total = plan->batch * (uint64_t)plan->n;
+    hipError_t e = hipSuccess;
+
+    if (plan->kind == FWA_NORMALIZE) {
+        // processor.rs:433-439: (a, b) = (buffer1, buffer2) if log2 n even else (buffer2, buffer1); returns b
+        fwa_buf *a = (plan->lg % 2 == 0) ? plan->src : plan->second;
+        fwa_buf *b = (plan->lg % 2 == 0) ? plan->second : plan->src;
+        e = fwa::launch_scale(static_cast<const v2f *>(a->p), static_cast<v2f *>(b->p), total,
+                              1.0f / (float)plan->n, st);
+        if (e != hipSuccess) return fail_hip(ctx, e, "normalize launch", FWA_ERR_LAUNCH);
+        if (result) *result = b;
+        return FWA_OK;
+    }
+
+    const int dir = (plan->kind == FWA_FORWARD) ? fwa::FWD : fwa::INV;
+    const float scale = (plan->kind == FWA_INVERSE_SCALED) ? 1.0f / (float)plan->n : 1.0f;  // ifft.wgsl:65-74
+    fwa_buf *res = result_buffer(plan);
+    if (result) *result = res;
+    if (total == 0) return FWA_OK;
+    v2f *a = static_cast<v2f *>(plan->src->p);
+    v2f *b = static_cast<v2f *>(plan->second->p);
+    v2f *out = static_cast<v2f *>(res->p);
+
+    switch (plan->path) {
+        case PATH_IDENTITY:
+            if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
+            break;
+        case PATH_LDS_SMALL:
+            e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
+            break;
+        case PATH_R2_GLOBAL:
+            for (uint32_t s = 0; s < plan->lg && e == hipSuccess; ++s) {
+                const v2f *from = (s % 2 == 0) ? a : b;
+                v2f *to = (s % 2 == 0) ? b : a;
+                e = fwa::launch_r2_stage(dir, from, to, plan->tw_half, plan->n, s, plan->batch,
+                                         (s + 1 == plan->lg) ? scale : 1.0f, st);
+            }
+            break;
+        case PATH_TWOPASS_1M: {
+            const uint64_t G = (uint64_t)plan->group;
+            const uint64_t n_groups = (plan->batch + G - 1) / G;
+            const size_t ns = plan->istreams.size();
+            if (ns) {
+                HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
+                for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
+            }
+            for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
+                const uint64_t t0 = g * G;
+                const uint32_t cnt = (uint32_t)((plan->batch - t0 < G) ? plan->batch - t0 : G);
+                const size_t si = ns ? (size_t)(g % ns) : 0;
+                hipStream_t s = ns ? plan->istreams[si] : st;
+                // ring region of this stream: slots [si*G, si*G + G); kernels index it by (t % ring_slots)
+                // through a per-launch base so that groups on different streams never share slots.
+                v2f *ring = plan->ring + (uint64_t)si * G * (1ull << 20);
+                // inside a group, transform t uses slot (t - t0): pass ring_slots = G and t_first offset
+                e = fwa::launch_p1_1m(dir, a + t0 * (1ull << 20), ring, plan->tw_inner, plan->tw_outer, (uint32_t)G, 0,
+                                      cnt, s);
+                if (e != hipSuccess) break;
+                e = fwa::launch_p2_1m(dir, ring, out + t0 * (1ull << 20), plan->tw_inner, (uint32_t)G, 0, cnt, scale,
+                                      s);
+            }
+            if (ns && e == hipSuccess) {
+                for (size_t i = 0; i < ns; ++i) {
+                    HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
+                    HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
+                }
+            }
+            break;
+        }
+        default:
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "plan path not implemented");
+    }
+    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
+    return FWA_OK;
+}
+
+int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
+{
+    if (!plan || !key || !value) return fail(plan ? plan->ctx : nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    const std::string k(key);
+    if (k == "batch") *value = (int64_t)plan->batch;
+    else if (k == "fft_len") *value = plan->n;
+    else if (k == "path") *value = plan->path;
+    else if (k == "group") *value = plan->group;
+    else if (k == "streams") *value = plan->n_streams;
+    else if (k == "scratch_bytes")
+        *value = (int64_t)(plan->ring_slots * (sizeof(v2f) << 20)) + (plan->second_owned ? (int64_t)plan->own_second.bytes : 0);
+    else if (k == "launches_per_exec") {
+        switch (plan->path) {
+            case PATH_TWOPASS_1M: *value = 2 * (int64_t)((plan->batch + plan->group - 1) / plan->group); break;
+            case PATH_R2_GLOBAL: *value = plan->lg; break;
+            case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
+            default: *value = 1;
+        }
+    } else return fail(plan->ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
+    return FWA_OK;
+}
+
+int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
+{
+    if (!plan || !key) return fail(plan ? plan->ctx : nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    if (plan->frozen) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "plan tunables are locked after the first exec");
+    const std::string k(key);
+    if (k == "group" || k == "streams") {
+        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 path");
+        if (value < 1 || value > 4096) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (k == "group") plan->group = value; else plan->n_streams = value;
+        return build_pipeline(plan);
+    }
+    if (k == "path") {
+        if (plan->kind == FWA_NORMALIZE) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
+        if (value == PATH_R2_GLOBAL && plan->n >= 2) {
+            // force the literal reference recurrence (one launch per stage)
+            if (!plan->tw_half) {
+                std::vector<v2f> h(plan->n / 2);
+                for (uint32_t i = 0; i < plan->n / 2; ++i) h[i] = tw_f64(i, plan->n);
+                int32_t st = upload_table(plan->ctx, h, &plan->tw_half);
+                if (st) return st;
+            }
+            if (!plan->second->p && plan->src->bytes) {
+                if (plan->second != &plan->own_second)
+                    return fail(plan->ctx, FWA_ERR_INVALID_ARG, "second buffer missing");
+                hipError_t e = hipMalloc(&plan->own_second.p, plan->src->bytes);
+                if (e != hipSuccess) return fail_hip(plan->ctx, e, "hipMalloc(second buffer)");
+                plan->own_second.bytes = plan->src->bytes;
+                plan->second_owned = true;
+            }
+            plan->path = PATH_R2_GLOBAL;
+            return FWA_OK;
+        }
+        return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "only path=2 (radix-2 global) can be forced");
+    }
+    return fail(plan->ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
+}
+
+// ---- events ----------------------------------------------------------------
+int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out)
+{
+    if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    hipEvent_t e;
+    HIP_TRY(ctx, hipEventCreate(&e));
+    fwa_event *ev = new (std::nothrow) fwa_event;
+    if (!ev) { (void)hipEventDestroy(e); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    ev->ctx = ctx; ev->e = e;
+    *out = ev;
+    return FWA_OK;
+}
+int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream)
+{
+    if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    HIP_TRY(ev->ctx, hipEventRecord(ev->e, raw(stream)));
+    return FWA_OK;
+}
+int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms)
+{
+    if (!start || !end || !ms) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(end->ctx, hipEventSynchronize(end->e));
+    HIP_TRY(end->ctx, hipEventElapsedTime(ms, start->e, end->e));
+    return FWA_OK;
+}
+int32_t fwa_event_destroy(fwa_event *ev)
+{
+    if (!ev) return FWA_OK;
+    (void)hipEventDestroy(ev->e);
+    delete ev;
+    return FWA_OK;
+}
+
+// ---- synthetic data / calibration -------------------------------------------
+int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform, uint32_t fft_len, float scale,
+                           fwa_stream *stream)
+{
+    if (!dst || !fft_len) return fail(dst ? dst->ctx : nullptr, FWA_ERR_INVALID_ARG, "dst NULL or fft_len 0");
+    hipError_t e = fwa::launch_fill(static_cast<v2f *>(dst->p), seed, first_transform * (uint64_t)fft_len,
+                                    dst->bytes / 8, scale, raw(stream));
+    if (e != hipSuccess) return fail_hip(dst->ctx, e, "fill launch", FWA_ERR_LAUNCH);
+    return FWA_OK;
+}
+
+int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_stream *stream)
+{
+    if (!dst || !src) return fail(nullptr, FWA_ERR_INVALID_ARG, "dst/src is NULL");
+    if (bytes > dst->bytes || bytes > src->bytes || (bytes & 15))
+        return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
+    hipError_t e = fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
+    if (e != hipSuccess) return fail_hip(dst->ctx, e, "copy launch", FWA_ERR_LAUNCH);
+    return FWA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+// kernels.h -- launch wrappers implemented in kernels.hip (internal to the library).
+#pragma once
+#include "cplx.h"
+
+namespace fwa {
+
+hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint32_t stage,
+                           uint64_t batch, float scale, hipStream_t st);
+hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                            hipStream_t st);
+hipError_t setup_1m_kernels();
+hipError_t launch_p1_1m(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
+                        uint32_t ring_slots, uint64_t t_first, uint32_t n_transforms, hipStream_t st);
+hipError_t launch_p2_1m(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t ring_slots,
+                        uint64_t t_first, uint32_t n_transforms, float scale, hipStream_t st);
+hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
+hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
+hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);
+
+}  // namespace fwa

@@ -1,0 +1,199 @@
+"""Device / Queue / Buffer / CommandEncoder: the wgpu objects the reference's
+callers touch (src/lib.rs:29-62, src/examples/basic.rs:6-122), mapped onto the
+C ABI.  Names and call order follow the reference so that the example loop
+
+    queue.write_buffer(src, 0, data); enc = device.create_command_encoder();
+    out = plan.proc(enc); enc.copy_buffer_to_buffer(out, 0, staging, 0, n);
+    queue.submit(enc.finish()); staging.map_read()
+
+reads the same here.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+
+class Buffer:
+    """wgpu::Buffer (examples/basic.rs:50-64).  Caller-owned device memory."""
+
+    def __init__(self, device, handle, borrowed=False):
+        self.device = device
+        self._h = handle
+        self._borrowed = borrowed  # handle owned by a plan: never freed from here
+
+    @property
+    def size(self):
+        return int(_ffi.lib().fwa_buf_size(self._h))
+
+    @property
+    def device_ptr(self):
+        return int(_ffi.lib().fwa_buf_device_ptr(self._h) or 0)
+
+    def destroy(self):
+        if self._h and not self._borrowed:
+            _ffi.lib().fwa_buf_free(self._h)
+        self._h = None
+
+    def map_read(self, offset=0, size=None, stream=None, dtype=np.complex64):
+        """map_async + poll(wait) + get_mapped_range (examples/basic.rs:105-122): blocking read-back."""
+        size = self.size - offset if size is None else size
+        out = np.empty(size // np.dtype(dtype).itemsize, dtype=dtype)
+        st = _ffi.lib().fwa_buf_download(out.ctypes.data_as(ctypes.c_void_p), self._h, offset, size,
+                                         stream._h if stream else None)
+        _ffi.check(st, self.device._h, "fwa_buf_download")
+        return out
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class CommandEncoder:
+    """wgpu::CommandEncoder: work recorded here runs in order on one HIP stream."""
+
+    def __init__(self, device, stream_handle, owned):
+        self.device = device
+        self._h = stream_handle
+        self._owned = owned
+
+    def copy_buffer_to_buffer(self, src, src_offset, dst, dst_offset, size):
+        st = _ffi.lib().fwa_buf_copy(dst._h, dst_offset, src._h, src_offset, size, self._h)
+        _ffi.check(st, self.device._h, "fwa_buf_copy")
+
+    def finish(self):
+        return self
+
+    def synchronize(self):
+        _ffi.check(_ffi.lib().fwa_stream_synchronize(self._h), self.device._h, "fwa_stream_synchronize")
+
+    def destroy(self):
+        if self._h and self._owned:
+            _ffi.lib().fwa_stream_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, device):
+        self.device = device
+        h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_event_create(device._h, ctypes.byref(h)), device._h, "fwa_event_create")
+        self._h = h
+
+    def record(self, encoder):
+        _ffi.check(_ffi.lib().fwa_event_record(self._h, encoder._h), self.device._h, "fwa_event_record")
+
+    def elapsed_ms(self, end):
+        ms = ctypes.c_float()
+        _ffi.check(_ffi.lib().fwa_event_elapsed_ms(self._h, end._h, ctypes.byref(ms)), self.device._h,
+                   "fwa_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().fwa_event_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Queue:
+    """wgpu::Queue (examples/basic.rs:73,92)."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def write_buffer(self, buffer, offset, data, encoder=None):
+        data = np.ascontiguousarray(data)
+        st = _ffi.lib().fwa_buf_upload(buffer._h, offset, data.ctypes.data_as(ctypes.c_void_p), data.nbytes,
+                                       encoder._h if encoder else None)
+        _ffi.check(st, self.device._h, "fwa_buf_upload")
+        if encoder is None:
+            self.device.poll()
+
+    def submit(self, command_buffer):
+        # work was enqueued as it was recorded; submit is the ordering point the reference has
+        return command_buffer
+
+
+class Device:
+    """wgpu::Device (+ Instance/Adapter): one per GPU ordinal."""
+
+    def __init__(self, ordinal=0):
+        h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_ctx_create(ordinal, ctypes.byref(h)), None, "fwa_ctx_create")
+        self._h = h
+        self.ordinal = ordinal
+        self._default = CommandEncoder(self, None, owned=False)  # null stream
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        cus = ctypes.c_int32()
+        mem = ctypes.c_uint64()
+        _ffi.check(_ffi.lib().fwa_ctx_device_info(self._h, name, 256, ctypes.byref(cus), ctypes.byref(mem)),
+                   self._h, "fwa_ctx_device_info")
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def create_buffer(self, size):
+        h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_buf_alloc(self._h, size, ctypes.byref(h)), self._h, "fwa_buf_alloc")
+        return Buffer(self, h)
+
+    def wrap_buffer(self, device_ptr, size):
+        """Zero-copy view of memory owned elsewhere (e.g. a torch tensor's data_ptr())."""
+        h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_buf_wrap(self._h, device_ptr, size, ctypes.byref(h)), self._h, "fwa_buf_wrap")
+        return Buffer(self, h)  # the handle is ours, the memory is not (fwa_buf_wrap)
+
+    def create_command_encoder(self, hip_stream=None):
+        h = ctypes.c_void_p()
+        if hip_stream is None:
+            _ffi.check(_ffi.lib().fwa_stream_create(self._h, ctypes.byref(h)), self._h, "fwa_stream_create")
+            return CommandEncoder(self, h, owned=True)
+        _ffi.check(_ffi.lib().fwa_stream_wrap(self._h, hip_stream, ctypes.byref(h)), self._h, "fwa_stream_wrap")
+        return CommandEncoder(self, h, owned=True)
+
+    def poll(self, encoder=None):
+        """device.poll(Maintain::wait()) (examples/basic.rs:106)."""
+        (encoder or self._default).synchronize()
+
+    def fill_synthetic(self, buffer, fft_len, seed=0x5EED, first_transform=0, scale=1.0, encoder=None):
+        st = _ffi.lib().fwa_fill_synthetic(buffer._h, seed, first_transform, fft_len, scale,
+                                           encoder._h if encoder else None)
+        _ffi.check(st, self._h, "fwa_fill_synthetic")
+
+    def calib_copy(self, dst, src, nbytes, encoder=None):
+        st = _ffi.lib().fwa_calib_copy(dst._h, src._h, nbytes, encoder._h if encoder else None)
+        _ffi.check(st, self._h, "fwa_calib_copy")
+
+    def destroy(self):
+        if self._h:
+            _ffi.lib().fwa_ctx_destroy(self._h)
+            self._h = None
+
+
+def device_count():
+    n = ctypes.c_int32()
+    st = _ffi.lib().fwa_device_count(ctypes.byref(n))
+    return n.value if st == 0 else 0
+
+
+def prepare_gpu(ordinal=0):
+    """src/lib.rs:29-62: returns (device, queue) or None when no adapter/device is usable."""
+    try:
+        dev = Device(ordinal)
+    except _ffi.FwaError as e:
+        if e.status == 5:  # FWA_ERR_NO_DEVICE
+            return None
+        raise
+    return dev, Queue(dev)

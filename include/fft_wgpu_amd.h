@@ -1,0 +1,149 @@
+/*
+ * fft_wgpu_amd.h -- C ABI of the MI355X-native batched 1-D complex fp32 FFT.
+ *
+ * This is the drop-in boundary for the compute path of the Rust crate
+ * TYPEmber/fft_wgpu.  The crate reaches its GPU through inline `wgpu` calls
+ * (its FFI seam `src/wgpu_helper.rs` is an empty file declared at
+ * `src/lib.rs:8`); every entry point below names the reference call it
+ * replaces.  Plain pointers and sizes only: no C++ types, no exceptions, no
+ * torch types cross this boundary.  INTEGRATION.md shows the Rust `extern "C"`
+ * block and the `Forward<'a>`-style wrappers a maintainer would add.
+ *
+ * Data layout: a buffer is `batch` transforms back to back, transform b at
+ * element offset b*fft_len, each element {f32 re, f32 im} interleaved, little
+ * endian (reference `src/lib.rs:10-15`, `src/kernel/fft4.wgsl:21-22`).
+ * Offsets and sizes are 64-bit (the reference truncates to u32:
+ * `src/processor.rs:30-31`).
+ *
+ * Threading: ctx / plan creation and destruction are not thread-safe.
+ * One in-flight fwa_plan_exec per plan (plans own scratch).  One ctx per
+ * device ordinal; multi-GPU = one process (or one ctx) per device.
+ *
+ * Errors: every function returns an fwa_status (0 = ok).  Nothing aborts or
+ * throws across the ABI.  fwa_last_error_string() gives detail.
+ */
+#ifndef FFT_WGPU_AMD_H
+#define FFT_WGPU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWA_ABI_VERSION 1
+
+typedef enum fwa_status {
+    FWA_OK = 0,
+    FWA_ERR_INVALID_ARG = 1,  /* non power-of-two fft_len, size not a multiple of 8*fft_len, NULL handle ... */
+    FWA_ERR_OUT_OF_MEMORY = 2,
+    FWA_ERR_HIP = 3,          /* HIP runtime call failed */
+    FWA_ERR_LAUNCH = 4,       /* kernel launch failed */
+    FWA_ERR_NO_DEVICE = 5,    /* no usable gfx950 device (reference: prepare_gpu -> None, src/lib.rs:43,59) */
+    FWA_ERR_UNSUPPORTED = 6
+} fwa_status;
+
+/* The four plan structs of reference src/processor.rs. */
+typedef enum fwa_plan_kind {
+    FWA_FORWARD = 0,           /* processor.rs:7-159   + kernel/fft4.wgsl    : unnormalised forward          */
+    FWA_INVERSE_SCALED = 1,    /* processor.rs:231-341 + kernel/ifft.wgsl    : inverse, 1/n fused            */
+    FWA_INVERSE_UNSCALED = 2,  /* processor.rs:566-670 + kernel/onlyifft.wgsl: inverse, no scale             */
+    FWA_NORMALIZE = 3          /* processor.rs:409-505 + kernel/normalize.wgsl: b[i] = a[i] / f32(fft_len)   */
+} fwa_plan_kind;
+
+typedef struct fwa_ctx fwa_ctx;       /* wgpu::Instance + Adapter + Device + Queue  (lib.rs:29-62)        */
+typedef struct fwa_stream fwa_stream; /* wgpu::CommandEncoder + Queue::submit + Device::poll              */
+typedef struct fwa_buf fwa_buf;       /* wgpu::Buffer                                                      */
+typedef struct fwa_plan fwa_plan;     /* Forward / Inverse / Onlyinverse / Normalize                       */
+typedef struct fwa_event fwa_event;   /* (no reference analogue: the reference has timestamp_writes: None) */
+
+/* ---- library ---------------------------------------------------------- */
+int32_t fwa_abi_version(void);
+/* Detail of the most recent failure on `ctx` (or of the last ctx-less call when ctx == NULL).
+ * The pointer stays valid until the next failing call on the same ctx. */
+const char *fwa_last_error_string(const fwa_ctx *ctx);
+const char *fwa_status_string(int32_t status);
+
+/* ---- device / queue : replaces lib.rs:29-62, examples/basic.rs:6-30 ---- */
+int32_t fwa_device_count(int32_t *count);
+int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out);
+int32_t fwa_ctx_destroy(fwa_ctx *ctx);
+/* name: NUL-terminated gcnArchName ("gfx950:..."), truncated to name_cap. */
+int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap,
+                            int32_t *compute_units, uint64_t *hbm_bytes);
+
+/* ---- stream : replaces create_command_encoder / submit / poll(wait)
+ *               (examples/basic.rs:76,92,105-106) ------------------------- */
+int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out);
+/* Wrap an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the null stream.
+ * The wrapped stream is not destroyed by fwa_stream_destroy. */
+int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out);
+int32_t fwa_stream_synchronize(fwa_stream *stream);
+int32_t fwa_stream_destroy(fwa_stream *stream);
+
+/* ---- buffers : replaces create_buffer / write_buffer / copy_buffer_to_buffer /
+ *                map_async+get_mapped_range (examples/basic.rs:50-64,73,84-90,105-122) */
+int32_t fwa_buf_alloc(fwa_ctx *ctx, uint64_t bytes, fwa_buf **out);
+/* Zero-copy interop: wrap device memory owned by someone else (never freed by fwa_buf_free). */
+int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **out);
+int32_t fwa_buf_free(fwa_buf *buf);
+int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint64_t bytes,
+                       fwa_stream *stream);
+int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes,
+                         fwa_stream *stream);
+int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint64_t src_offset,
+                     uint64_t bytes, fwa_stream *stream);
+void *fwa_buf_device_ptr(const fwa_buf *buf);
+uint64_t fwa_buf_size(const fwa_buf *buf);
+
+/* ---- plans : replaces X::new / X::proc of processor.rs ------------------
+ * fwa_plan_create mirrors
+ *   Forward::new(&device,&queue,&src,fft_len)              processor.rs:22-27   (src2 == NULL)
+ *   Inverse::new(&device,&queue,&src,fft_len)              processor.rs:245-250 (src2 == NULL)
+ *   Onlyinverse::new(&device,&queue,&src,&src2,fft_len)    processor.rs:580-586 (src2 required)
+ *   Normalize::new(&device,&queue,&buffer1,&buffer2,fft_len) processor.rs:422-428 (src2 required)
+ * batch is implicit: fwa_buf_size(src) / 8 / fft_len.  Buffers stay caller-owned and must
+ * outlive the plan.  Rejected with FWA_ERR_INVALID_ARG: fft_len not a power of two (or 0),
+ * size(src) % (8*fft_len) != 0, size(src2) != size(src), missing/extra src2.
+ *
+ * fwa_plan_exec mirrors X::proc(&self, &mut encoder) -> &wgpu::Buffer
+ * (processor.rs:110,293,467,622): asynchronous and stream-ordered, allocates nothing, and
+ * returns in *result the buffer that will hold the natural-order output, following the
+ * reference's rule (processor.rs:153-157,335-339,664-668): `src` when log2(fft_len) is even,
+ * otherwise the second buffer (plan-owned for FORWARD / INVERSE_SCALED, caller's src2 for
+ * INVERSE_UNSCALED).  NORMALIZE reads (buffer1 if log2 even else buffer2) and writes and returns
+ * the other (processor.rs:433-439,504).  The contents of the non-result buffer are unspecified
+ * afterwards (the reference clobbers its input).  *result may be NULL-checked by callers that
+ * do not need it: pass result == NULL. */
+int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *src,
+                        fwa_buf *src2_or_null, fwa_plan **out);
+int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result);
+int32_t fwa_plan_destroy(fwa_plan *plan);
+
+/* Introspection / tuning (no reference analogue).  Keys for fwa_plan_get_i64:
+ *   "batch", "fft_len", "path" (0 lds-small, 1 two-pass 2^20, 2 radix-2 global, 3 normalize, 4 identity),
+ *   "launches_per_exec", "scratch_bytes", "group" (transforms per pipeline group).
+ * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "path". */
+int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
+int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
+
+/* ---- measurement helpers (HIP events on the launch stream) -------------- */
+int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out);
+int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream);
+/* Blocks until `end` has completed. */
+int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms);
+int32_t fwa_event_destroy(fwa_event *ev);
+
+/* Deterministic synthetic input generated on the device: sample i of
+ * transform t is a pure function of (seed, (first_transform+t)*fft_len + i); re, im uniform
+ * in [-1,1) times `scale`.  Bit-identical to oracle/ref_fft.c:fwo_gen_input. */
+int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform,
+                           uint32_t fft_len, float scale, fwa_stream *stream);
+/* float4 streaming copy of `bytes` from src to dst (the measured-ceiling calibration kernel). */
+int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_stream *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFT_WGPU_AMD_H */
