@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""tools/sweep.py -- GPU-side tuning sweep (not part of the product path or the tests).
+
+Measures (HIP events, median of a few repetitions):
+  * float4 copy rate vs footprint (what the Infinity Cache serves vs HBM),
+  * the N=2^20 plan at several (group, streams) settings.
+Writes one JSON line per measurement to stdout.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fft_wgpu_amd as fw  # noqa: E402
+
+
+def med(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--settings", type=str, default="8x1,8x2,8x3,16x2,16x3,32x2,4x2,4x4,64x2")
+    ap.add_argument("--copy", action="store_true")
+    args = ap.parse_args()
+    dev, queue = fw.prepare_gpu(0)
+    n = 1 << 20
+    nbytes = n * args.batch * 8
+    buf = dev.create_buffer(nbytes)
+    enc = dev.create_command_encoder()
+    dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
+    enc.synchronize()
+
+    if args.copy:
+        for mib in (8, 16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 4096):
+            half = mib << 20
+            if 2 * half > nbytes:
+                break
+            s = dev.wrap_buffer(buf.device_ptr, half)
+            d = dev.wrap_buffer(buf.device_ptr + half, half)
+            iters = max(3, min(200, (8 << 30) // half))
+            for _ in range(2):
+                dev.calib_copy(d, s, half, encoder=enc)
+            a, b = fw.Event(dev), fw.Event(dev)
+            a.record(enc)
+            for _ in range(iters):
+                dev.calib_copy(d, s, half, encoder=enc)
+            b.record(enc)
+            ms = a.elapsed_ms(b) / iters
+            print(json.dumps({"what": "copy", "footprint_MiB": 2 * mib, "us": ms * 1e3,
+                              "GBps_rw": 2 * half / (ms * 1e-3) / 1e9}), flush=True)
+        dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
+        enc.synchronize()
+
+    for s in args.settings.split(","):
+        g, ns = (int(v) for v in s.split("x"))
+        plan = fw.Forward(dev, queue, buf, n)
+        plan.set("group", g)
+        plan.set("streams", ns)
+        dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
+        plan.proc(enc)
+        enc.synchronize()
+        times = []
+        for _ in range(args.reps):
+            a, b = fw.Event(dev), fw.Event(dev)
+            a.record(enc)
+            plan.proc(enc)
+            b.record(enc)
+            times.append(a.elapsed_ms(b))
+        ms = med(times)
+        print(json.dumps({"what": "fft1m", "group": g, "streams": ns, "batch": args.batch, "ms": ms,
+                          "ms_all": times, "Gsamples_s": n * args.batch / (ms * 1e-3) / 1e9,
+                          "roofline_frac": 16 * n * args.batch / (ms * 1e-3) / 8e12}), flush=True)
+        plan.destroy()
+
+
+if __name__ == "__main__":
+    main()
