@@ -134,7 +134,9 @@ class Device:
         _ffi.check(_ffi.lib().fwa_ctx_create(ordinal, ctypes.byref(h)), None, "fwa_ctx_create")
         self._h = h
         self.ordinal = ordinal
-        self._default = CommandEncoder(self, None, owned=False)  # null stream
+        d = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_stream_wrap(h, None, ctypes.byref(d)), h, "fwa_stream_wrap")
+        self._default = CommandEncoder(self, d, owned=True)  # the HIP null stream
 
     def info(self):
         name = ctypes.create_string_buffer(256)
