@@ -47,6 +47,7 @@ enum fwa_path : int64_t {
     PATH_R2_GLOBAL = 2,
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,
+    PATH_FUSED_1M = 5,  // in-place persistent pipeline, one launch per exec
 };
 
 struct fwa_plan {
@@ -70,6 +71,10 @@ struct fwa_plan {
     int64_t group = 8;             // transforms per launch pair
     int64_t n_streams = 2;         // internal streams the groups alternate over
     uint64_t ring_slots = 0;
+    // fused 2^20 pipeline
+    uint32_t *fused_ctl = nullptr;
+    int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
+    int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
@@ -133,6 +138,7 @@ void release_pipeline(fwa_plan *p)
     p->idone.clear();
     if (p->ev_fork) { (void)hipEventDestroy(p->ev_fork); p->ev_fork = nullptr; }
     if (p->ring) { (void)hipFree(p->ring); p->ring = nullptr; }
+    if (p->fused_ctl) { (void)hipFree(p->fused_ctl); p->fused_ctl = nullptr; }
 }
 
 // Allocate the scratch ring and the internal streams of the 2^20 pipeline (first exec or plan creation).
@@ -140,6 +146,13 @@ int32_t build_pipeline(fwa_plan *p)
 {
     fwa_ctx *ctx = p->ctx;
     release_pipeline(p);
+    if (p->path == PATH_FUSED_1M) {
+        if (p->batch == 0) return FWA_OK;
+        if (p->wgs <= 0) p->wgs = 2 * (int64_t)ctx->prop.multiProcessorCount;
+        if (p->wgs < 64) p->wgs = 64;  // progress guarantee of k_fused_1m needs >= 64 resident workgroups
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->fused_ctl), fwa::fused_ctl_bytes(p->batch)));
+        return FWA_OK;
+    }
     if (p->group < 1) p->group = 1;
     if ((uint64_t)p->group > p->batch && p->batch) p->group = (int64_t)p->batch;
     const uint64_t n_groups = p->batch ? (p->batch + p->group - 1) / p->group : 0;
@@ -420,7 +433,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
 
     if (fft_len == 1) p->path = PATH_IDENTITY;
     else if (fft_len <= 4096) p->path = PATH_LDS_SMALL;
-    else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;
+    else if (fft_len == (1u << 20)) p->path = (p->batch < (1u << 24)) ? PATH_FUSED_1M : PATH_TWOPASS_1M;
     else p->path = PATH_R2_GLOBAL;
 
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
@@ -445,7 +458,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         for (uint32_t k = 0; k < fft_len / 2; ++k) h[k] = tw_f64(k, fft_len);
         st = upload_table(ctx, h, &p->tw_half);
         if (st) return bail(st);
-    } else if (p->path == PATH_TWOPASS_1M) {
+    } else if (p->path == PATH_TWOPASS_1M || p->path == PATH_FUSED_1M) {
         if (!ctx->setup_1m_done) {
             hipError_t e = fwa::setup_1m_kernels();
             if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
@@ -523,6 +536,11 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                                          (s + 1 == plan->lg) ? scale : 1.0f, st);
             }
             break;
+        case PATH_FUSED_1M:
+            // in place: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
+            e = fwa::launch_fused_1m(dir, a, plan->tw_inner, plan->tw_outer, plan->fused_ctl, (uint32_t)plan->batch,
+                                     (uint32_t)plan->depth, (uint32_t)plan->wgs, scale, st);
+            break;
         case PATH_TWOPASS_1M: {
             const uint64_t G = (uint64_t)plan->group;
             const uint64_t n_groups = (plan->batch + G - 1) / G;
@@ -570,11 +588,26 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "path") *value = plan->path;
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
+    else if (k == "depth") *value = plan->depth;
+    else if (k == "wgs") *value = plan->wgs;
+    else if (k == "device_error") {
+        // bounded-spin timeout flag of the fused kernel (0 in every healthy run); synchronises the device
+        *value = 0;
+        if (plan->fused_ctl) {
+            uint32_t w = 0;
+            HIP_TRY(plan->ctx, hipDeviceSynchronize());
+            HIP_TRY(plan->ctx, hipMemcpy(&w, plan->fused_ctl + 1, sizeof(w), hipMemcpyDeviceToHost));
+            *value = w;
+        }
+    }
     else if (k == "scratch_bytes")
-        *value = (int64_t)(plan->ring_slots * (sizeof(v2f) << 20)) + (plan->second_owned ? (int64_t)plan->own_second.bytes : 0);
+        *value = (int64_t)(plan->ring_slots * (sizeof(v2f) << 20)) +
+                 (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
+                 (plan->fused_ctl ? (int64_t)fwa::fused_ctl_bytes(plan->batch) : 0);
     else if (k == "launches_per_exec") {
         switch (plan->path) {
             case PATH_TWOPASS_1M: *value = 2 * (int64_t)((plan->batch + plan->group - 1) / plan->group); break;
+            case PATH_FUSED_1M: *value = 1; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
             default: *value = 1;
@@ -589,13 +622,23 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (plan->frozen) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "plan tunables are locked after the first exec");
     const std::string k(key);
     if (k == "group" || k == "streams") {
-        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 path");
+        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 path");
         if (value < 1 || value > 4096) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
         if (k == "group") plan->group = value; else plan->n_streams = value;
         return build_pipeline(plan);
     }
+    if (k == "depth" || k == "wgs") {
+        if (plan->path != PATH_FUSED_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the fused 2^20 path");
+        if (value < 1 || value > 65536) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (k == "depth") plan->depth = value; else plan->wgs = value < 64 ? 64 : value;
+        return FWA_OK;
+    }
     if (k == "path") {
         if (plan->kind == FWA_NORMALIZE) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
+        if ((value == PATH_TWOPASS_1M || value == PATH_FUSED_1M) && plan->n == (1u << 20)) {
+            plan->path = value;
+            return build_pipeline(plan);
+        }
         if (value == PATH_R2_GLOBAL && plan->n >= 2) {
             // force the literal reference recurrence (one launch per stage)
             if (!plan->tw_half) {
@@ -615,7 +658,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             plan->path = PATH_R2_GLOBAL;
             return FWA_OK;
         }
-        return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "only path=2 (radix-2 global) can be forced");
+        return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "only path=2 (radix-2 global) or, at n=2^20, 1/5 can be forced");
     }
     return fail(plan->ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
 }

@@ -137,6 +137,29 @@ constexpr int XCH_BYTES = 65536;
 constexpr int TWI_BYTES = 8192;
 constexpr int TWO_BYTES = 8192;
 
+// Buffer (SRD) addressing: one 32-bit per-lane byte offset + a scalar offset per access, so the 32 loads
+// and 32 stores of a tile need no per-access VALU address math (cdna_hip_programming.md T8/T20).  The
+// descriptor covers exactly one 8-MiB transform; out-of-range lanes would read 0 / drop the store.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr uint32_t TRANSFORM_BYTES = 8u << 20;
+// cache-policy bits of the aux operand (gfx940+): sc0 = 1, nt = 2, sc1 = 16
+constexpr int AUX_DEFAULT = 0, AUX_NT = 2, AUX_SC1 = 16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const v2f *transform_base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(transform_base), 0, TRANSFORM_BYTES, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ v2f buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
+}
+
 template <int DIR>
 __device__ __forceinline__ void stage1_fft_twiddle(v2f (&x)[32], const v2f *twi, uint32_t q)
 {
@@ -149,36 +172,25 @@ __device__ __forceinline__ void stage1_fft_twiddle(v2f (&x)[32], const v2f *twi,
     });
 }
 
-template <int DIR>
-__global__ __launch_bounds__(512, 4) void k_p1_1m(const v2f *__restrict__ src, v2f *__restrict__ ring,
-                                                  const v2f *__restrict__ tw_inner,
-                                                  const v2f *__restrict__ tw_outer, uint32_t ring_slots,
-                                                  uint64_t t_first)
+// One pass-1 tile: column FFTs.  `in`/`out` are the (wave-uniform) bases of a 1024x1024 row-major
+// transform; they may be the same transform (in-place: every load of the workgroup completes before the
+// first exchange barrier, every store is issued after the last one).
+// Requires: twi loaded; `two` free to overwrite (all threads past their previous use).
+template <int DIR, int AUX_IN, int AUX_OUT>
+__device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, const v2f *tw_outer_tile,
+                                        float *xch, const v2f *twi, v2f *two, uint32_t tid)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *xch = reinterpret_cast<float *>(smem);
-    v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
-    v2f *two = reinterpret_cast<v2f *>(smem + XCH_BYTES + TWI_BYTES);
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t c = tid & 15;   // column inside the tile
-    const uint32_t q = tid >> 4;   // n' before the exchange, k1 after it
-    const uint32_t tile = blockIdx.x & 63;
-    const uint64_t t_local = blockIdx.x >> 6;
-    const uint64_t t = t_first + t_local;
-
-    // uniform (scalar) base + 32-bit per-thread offset: keeps addresses out of VGPR pairs
-    const v2f *in = src + t * (1ull << 20) + 16 * tile;
-    const uint32_t off = q * 1024 + c;
+    const uint32_t c = tid & 15;  // column inside the tile
+    const uint32_t q = tid >> 4;  // n' before the exchange, k1 after it
+    const uint32_t voff = (q * 1024 + c) * 8;
+    const uint32_t soff = tile * 128;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in), rout = make_rsrc(out);
     v2f x[32];
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        x[j] = (in + j * 32768)[off];
+        x[j] = buf_load<AUX_IN>(rin, voff, soff + j * 262144);
     });
-
-    // tables -> LDS (16 B per thread each)
-    reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
-    reinterpret_cast<v4f *>(two)[tid] = reinterpret_cast<const v4f *>(tw_outer + (size_t)tile * 1024)[tid];
+    reinterpret_cast<v4f *>(two)[tid] = reinterpret_cast<const v4f *>(tw_outer_tile)[tid];
     __syncthreads();
 
     stage1_fft_twiddle<DIR>(x, twi, q);
@@ -208,40 +220,34 @@ __global__ __launch_bounds__(512, 4) void k_p1_1m(const v2f *__restrict__ src, v
 
     // four-step twiddle W_N^{n2*K1} = A[q][c] * B[k2][c]
     const v2f A = two[q * 16 + c];
-    v2f *out = ring + (t % ring_slots) * (1ull << 20) + 16 * tile;
     static_for<0, 32>([&](auto k_) {
         constexpr int k2 = decltype(k_)::value;
         const v2f w = cmul(A, two[512 + k2 * 16 + c]);
-        (out + k2 * 32768)[off] = cmul_tw<DIR>(x[brev<32>(k2)], w);
+        buf_store<AUX_OUT>(cmul_tw<DIR>(x[brev<32>(k2)], w), rout, voff, soff + k2 * 262144);
     });
 }
 
-template <int DIR>
-__global__ __launch_bounds__(512, 4) void k_p2_1m(const v2f *__restrict__ ring, v2f *__restrict__ dst,
-                                                  const v2f *__restrict__ tw_inner, uint32_t ring_slots,
-                                                  uint64_t t_first, float scale)
+// One pass-2 tile: row FFTs + transposed store.  `in`/`out` are wave-uniform transform bases; the tile
+// reads rows [16*tile, 16*tile+16) and writes columns [16*tile, 16*tile+16).  after_load() runs once every load of the calling thread
+// has been issued and before the first barrier; before_store() runs right before the first store.
+// The in-place fused kernel uses them for the "all 64 tiles loaded" hand-shake.
+template <int DIR, int AUX_IN, int AUX_OUT, class AfterLoad, class BeforeStore>
+__device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, float scale, float *xch,
+                                        const v2f *twi, uint32_t tid, AfterLoad after_load,
+                                        BeforeStore before_store)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *xch = reinterpret_cast<float *>(smem);
-    v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x & 63;
-    const uint64_t t = t_first + (blockIdx.x >> 6);
-
     // before the exchange: lane = n' (32 consecutive samples of one row), r = row in the tile
     const uint32_t np = tid & 31;
     const uint32_t r = tid >> 5;
-    const v2f *in = ring + (t % ring_slots) * (1ull << 20) + (uint64_t)(16 * tile) * 1024;
-    const uint32_t off_in = r * 1024 + np;
+    const uint32_t voff_in = (r * 1024 + np) * 8;
+    const uint32_t soff_in = tile * 131072;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in), rout = make_rsrc(out);
     v2f x[32];
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        x[j] = (in + 32 * j)[off_in];
+        x[j] = buf_load<AUX_IN>(rin, voff_in, soff_in + j * 256);
     });
-
-    reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
-    __syncthreads();
+    after_load();
 
     stage1_fft_twiddle<DIR>(x, twi, np);
 
@@ -273,12 +279,167 @@ __global__ __launch_bounds__(512, 4) void k_p2_1m(const v2f *__restrict__ ring, 
 
     fft_reg<32, DIR>(x);  // x[brev(k2)] = row FFT output K2 = k1p + 32*k2
 
-    v2f *out = dst + t * (1ull << 20) + 16 * tile;
-    const uint32_t off_out = k1p * 1024 + r2;
+    before_store();
+    const uint32_t voff_out = (k1p * 1024 + r2) * 8;
+    const uint32_t soff_out = tile * 128;
     static_for<0, 32>([&](auto k_) {
         constexpr int k2 = decltype(k_)::value;
-        (out + k2 * 32768)[off_out] = x[brev<32>(k2)] * scale;
+        buf_store<AUX_OUT>(x[brev<32>(k2)] * scale, rout, voff_out, soff_out + k2 * 262144);
     });
+}
+
+template <int DIR>
+__global__ __launch_bounds__(512, 4) void k_p1_1m(const v2f *__restrict__ src, v2f *__restrict__ ring,
+                                                  const v2f *__restrict__ tw_inner,
+                                                  const v2f *__restrict__ tw_outer, uint32_t ring_slots,
+                                                  uint64_t t_first)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xch = reinterpret_cast<float *>(smem);
+    v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
+    v2f *two = reinterpret_cast<v2f *>(smem + XCH_BYTES + TWI_BYTES);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x & 63;
+    const uint64_t t = t_first + (blockIdx.x >> 6);
+    reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
+    p1_tile<DIR, AUX_DEFAULT, AUX_DEFAULT>(src + t * (1ull << 20), ring + (t % ring_slots) * (1ull << 20), tile,
+                                           tw_outer + (size_t)tile * 1024, xch, twi, two, tid);
+}
+
+template <int DIR>
+__global__ __launch_bounds__(512, 4) void k_p2_1m(const v2f *__restrict__ ring, v2f *__restrict__ dst,
+                                                  const v2f *__restrict__ tw_inner, uint32_t ring_slots,
+                                                  uint64_t t_first, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xch = reinterpret_cast<float *>(smem);
+    v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x & 63;
+    const uint64_t t = t_first + (blockIdx.x >> 6);
+    reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
+    p2_tile<DIR, AUX_DEFAULT, AUX_DEFAULT>(ring + (t % ring_slots) * (1ull << 20), dst + t * (1ull << 20), tile, scale,
+                                           xch, twi, tid, [] { __syncthreads(); }, [] {});
+}
+
+// ---------------------------------------------------------------------------
+// Fused, in-place, persistent 2^20 pipeline: ONE launch per exec, no scratch.
+//
+// Workgroups pull tickets from one counter.  Ticket order interleaves pass-1 tiles of transform t
+// with pass-2 tiles of transform t-D, so HBM reads (pass 1), cache-resident intermediate traffic and
+// HBM writes (pass 2) overlap continuously.  Pass 1 overwrites its column tile in place with Y; pass 2
+// reads 16 rows of Y and writes the 16-column tile of X over the same transform.  Because pass 2
+// transposes, a pass-2 tile may only store once ALL 64 pass-2 tiles of that transform hold their rows in
+// registers: `loaded[t]`.  `done1[t]` counts finished pass-1 tiles.
+//
+// Progress: tickets are handed out in order; pass-1 tiles wait for nothing; a pass-2 tile waits only for
+// tickets of its own transform or lower.  The dequeued tickets always form a prefix, at most one
+// transform is partially dequeued, so at most 63 workgroups can be parked in the loaded[] wait: any
+// launch with >= 64 resident workgroups makes progress.  Spins are bounded (ctl->error) regardless.
+// Visibility between workgroups follows cdna_hip_programming.md Guideline 16 (agent-scope release by the
+// producer after every wave drained its stores; relaxed poll + one agent-scope acquire by the consumer).
+// ---------------------------------------------------------------------------
+struct FusedCtl {
+    uint32_t ticket;
+    uint32_t error;
+    uint32_t pad[30];
+    // followed by done1[batch], loaded[batch]
+};
+
+__device__ __forceinline__ bool spin_until_64(const uint32_t *p, uint32_t *err)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 64u) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: never in a healthy run
+            __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+template <int DIR, int P1_IN = AUX_DEFAULT, int P1_OUT = AUX_DEFAULT, int P2_IN = AUX_DEFAULT, int P2_OUT = AUX_DEFAULT>
+__global__ __launch_bounds__(512, 4) void k_fused_1m(v2f *data, const v2f *__restrict__ tw_inner,
+                                                     const v2f *__restrict__ tw_outer, uint32_t *ctl_words,
+                                                     uint32_t batch, uint32_t depth, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xch = reinterpret_cast<float *>(smem);
+    v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
+    v2f *two = reinterpret_cast<v2f *>(smem + XCH_BYTES + TWI_BYTES);
+    uint32_t *ticket = ctl_words;
+    uint32_t *err = ctl_words + 1;
+    uint32_t *done1 = ctl_words + 32;
+    uint32_t *loaded = done1 + batch;
+
+    reinterpret_cast<v4f *>(twi)[threadIdx.x] = reinterpret_cast<const v4f *>(tw_inner)[threadIdx.x];
+
+    const uint32_t total = 128u * batch;
+    const uint32_t prologue = 64u * depth;             // pass-1 tiles of transforms 0..depth-1
+    const uint32_t steady = 128u * (batch - depth);    // interleaved region
+
+    for (;;) {
+        // Opaque per-iteration copy of the thread id: without it LICM hoists ~100 lane-constant LDS/global
+        // offsets out of the persistent loop and spills them (cdna_hip_programming.md, attention pitfalls).
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (tid == 0)
+            reinterpret_cast<uint32_t *>(xch)[0] =
+                __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // readfirstlane: the ticket is wave-uniform, keep everything derived from it in SGPRs
+        const uint32_t k = __builtin_amdgcn_readfirstlane(reinterpret_cast<uint32_t *>(xch)[0]);
+        __syncthreads();  // xch is reused by the exchange below
+        if (k >= total) break;
+
+        uint32_t pass, t, tile;
+        if (k < prologue) {
+            pass = 1; t = k >> 6; tile = k & 63;
+        } else if (k - prologue < steady) {
+            const uint32_t kk = k - prologue;
+            const uint32_t s = kk >> 7, r = kk & 127;
+            tile = r >> 1;
+            if ((r & 1) == 0) { pass = 1; t = s + depth; } else { pass = 2; t = s; }
+        } else {
+            const uint32_t kk = k - prologue - steady;
+            pass = 2; t = (batch - depth) + (kk >> 6); tile = kk & 63;
+        }
+        v2f *base = data + (uint64_t)t * (1ull << 20);
+
+        if (pass == 1) {
+            p1_tile<DIR, P1_IN, P1_OUT>(base, base, tile, tw_outer + (size_t)tile * 1024, xch, twi, two, tid);
+            // publish: every wave drains its stores, then one lane releases at agent scope and counts
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&done1[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (tid == 0) {
+                spin_until_64(&done1[t], err);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            p2_tile<DIR, P2_IN, P2_OUT>(
+                base, base, tile, scale, xch, twi, tid,
+                [&] {
+                    // this tile's rows are in registers: tell the other 63 tiles of the transform
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(&loaded[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                },
+                [&] {
+                    if (tid == 0) spin_until_64(&loaded[t], err);
+                    __syncthreads();
+                });
+            // the next iteration's first barrier orders these stores' issue after everything above;
+            // nothing in this launch reads X, the kernel boundary publishes it.
+        }
+    }
 }
 
 hipError_t setup_1m_kernels()
@@ -295,7 +456,34 @@ hipError_t setup_1m_kernels()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_p2_1m<INV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             XCH_BYTES + TWI_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_1m<FWD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, XCH_BYTES + TWI_BYTES + TWO_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_1m<INV>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, XCH_BYTES + TWI_BYTES + TWO_BYTES);
     return e;
+}
+
+size_t fused_ctl_bytes(uint64_t batch) { return sizeof(uint32_t) * (32 + 2 * batch); }
+
+hipError_t launch_fused_1m(int dir, v2f *data, const v2f *tw_inner, const v2f *tw_outer, uint32_t *ctl,
+                           uint32_t batch, uint32_t depth, uint32_t n_workgroups, float scale, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    if (depth < 1) depth = 1;
+    if (depth > batch) depth = batch;
+    hipError_t e = hipMemsetAsync(ctl, 0, fused_ctl_bytes(batch), st);
+    if (e != hipSuccess) return e;
+    const uint32_t max_useful = 128u * batch;
+    if (n_workgroups > max_useful) n_workgroups = max_useful;
+    const dim3 grid(n_workgroups), block(512);
+    const size_t lds = XCH_BYTES + TWI_BYTES + TWO_BYTES;
+    if (dir == FWD)
+        hipLaunchKernelGGL(k_fused_1m<FWD>, grid, block, lds, st, data, tw_inner, tw_outer, ctl, batch, depth, scale);
+    else
+        hipLaunchKernelGGL(k_fused_1m<INV>, grid, block, lds, st, data, tw_inner, tw_outer, ctl, batch, depth, scale);
+    return hipGetLastError();
 }
 
 hipError_t launch_p1_1m(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,

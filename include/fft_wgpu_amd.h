@@ -122,9 +122,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result);
 int32_t fwa_plan_destroy(fwa_plan *plan);
 
 /* Introspection / tuning (no reference analogue).  Keys for fwa_plan_get_i64:
- *   "batch", "fft_len", "path" (0 lds-small, 1 two-pass 2^20, 2 radix-2 global, 3 normalize, 4 identity),
- *   "launches_per_exec", "scratch_bytes", "group" (transforms per pipeline group).
- * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "path". */
+ *   "batch", "fft_len", "path" (0 lds-small, 1 two-launch 2^20, 2 radix-2 global, 3 normalize, 4 identity,
+ *   5 fused in-place 2^20), "launches_per_exec", "scratch_bytes", "group", "streams" (two-launch path),
+ *   "depth", "wgs" (fused path), "device_error" (synchronises; non-zero = a bounded device spin timed out).
+ * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "depth", "wgs", "path". */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 

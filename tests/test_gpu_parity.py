@@ -39,7 +39,7 @@ def _check(oracle, y, r, n, tol=REL_TOL):
     return worst
 
 
-def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None):
+def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=None, wgs=None):
     """reference call sequence (examples/basic.rs:73-122): write_buffer -> proc -> read back"""
     src = _upload(fw, dev, queue, x)
     src2 = dev.create_buffer(x.nbytes) if kind in ("Onlyinverse",) else None
@@ -52,11 +52,16 @@ def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None):
         plan.set("group", group)
     if streams is not None:
         plan.set("streams", streams)
+    if depth is not None:
+        plan.set("depth", depth)
+    if wgs is not None:
+        plan.set("wgs", wgs)
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
     y = out.map_read(stream=enc)
     which = 0 if out is src else 1
+    assert plan.get("device_error") == 0
     return y, which, plan
 
 
@@ -150,13 +155,18 @@ def test_config_c1_n1024_batch1(gpu, oracle):
         mx, l2, np.abs(y - yr).max() / np.abs(yr).max()))
 
 
-@pytest.mark.parametrize("batch,group,streams", [(1, 8, 2), (3, 2, 2), (5, 2, 1), (17, 4, 3)])
-def test_config_c2_n1m(gpu, oracle, batch, group, streams):
+# fused in-place pipeline (path 5, the default): (batch, depth, workgroups); two-launch ring (path 1): (batch, group, streams)
+@pytest.mark.parametrize("batch,path,a,b", [(1, 5, 4, 512), (3, 5, 1, 512), (5, 5, 2, 64), (17, 5, 4, 512),
+                                            (40, 5, 6, 300), (9, 5, 16, 512),
+                                            (1, 1, 8, 2), (3, 1, 2, 2), (5, 1, 2, 1), (17, 1, 4, 3)])
+def test_config_c2_n1m(gpu, oracle, batch, path, a, b):
     fw, dev, queue = gpu
     n = 1 << 20
     x = oracle.gen_input(n, batch)
-    y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=group, streams=streams)
-    assert which == 0 and plan.get("path") == 1
+    kw = dict(depth=a, wgs=b) if path == 5 else dict(path=1, group=a, streams=b)
+    group, streams = a, b
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n, **kw)
+    assert which == 0 and plan.get("path") == path
     r = oracle.dft_f64(x, n, -1)
     mx, l2 = _check(oracle, y, r, n)
     print("C2 batch %d: max_rel %.3g rel_l2 %.3g" % (batch, mx, l2))
@@ -166,7 +176,7 @@ def test_config_c2_n1m(gpu, oracle, batch, group, streams):
         y1, _, _ = _run(fw, dev, queue, "Forward", x[b * n:(b + 1) * n], n)
         assert np.array_equal(y1.view(np.uint32), y[b * n:(b + 1) * n].view(np.uint32))
     # inverse family on the fast path
-    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=group, streams=streams)
+    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, **kw)
     _check(oracle, z, x.astype(np.complex128), n)
 
 
@@ -175,9 +185,12 @@ def test_n1m_matches_literal_recurrence(gpu, oracle):
     n = 1 << 20
     x = oracle.gen_input(n, 2, first_transform=11)
     y_fast, _, _ = _run(fw, dev, queue, "Forward", x, n)
+    y_two, _, _ = _run(fw, dev, queue, "Forward", x, n, path=1)
     y_lit, _, _ = _run(fw, dev, queue, "Forward", x, n, path=2)
     d = np.abs(y_fast.astype(np.complex128) - y_lit).max() / np.abs(y_lit).max()
     assert d <= REL_TOL, d
+    # fused in-place and two-launch pipelines run the same arithmetic: bit-identical
+    assert np.array_equal(y_fast.view(np.uint32), y_two.view(np.uint32))
 
 
 def test_config_c5_n16m_batch1(gpu, oracle):
@@ -256,7 +269,7 @@ def test_config_c3_full_size_sampled(gpu, oracle):
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     enc.synchronize()
-    assert out is buf
+    assert out is buf and plan.get("device_error") == 0
     rng = np.random.default_rng(7)
     sample = [0, batch - 1] + sorted(rng.choice(np.arange(1, batch - 1), 14, replace=False).tolist())
     worst = 0.0

@@ -24,7 +24,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--settings", type=str, default="8x1,8x2,8x3,16x2,16x3,32x2,4x2,4x4,64x2")
+    ap.add_argument("--settings", type=str, default="8x2", help="two-launch path: GROUPxSTREAMS,...")
+    ap.add_argument("--fused", type=str, default="4x512,2x512,3x512,6x512,8x512,12x512,4x256,4x384",
+                    help="fused path: DEPTHxWORKGROUPS,...")
     ap.add_argument("--copy", action="store_true")
     args = ap.parse_args()
     dev, queue = fw.prepare_gpu(0)
@@ -56,11 +58,17 @@ def main():
         dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
         enc.synchronize()
 
-    for s in args.settings.split(","):
+    runs = [("two", s) for s in args.settings.split(",") if s] + [("fused", s) for s in args.fused.split(",") if s]
+    for kind, s in runs:
         g, ns = (int(v) for v in s.split("x"))
         plan = fw.Forward(dev, queue, buf, n)
-        plan.set("group", g)
-        plan.set("streams", ns)
+        if kind == "two":
+            plan.set("path", 1)
+            plan.set("group", g)
+            plan.set("streams", ns)
+        else:
+            plan.set("depth", g)
+            plan.set("wgs", ns)
         dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
         plan.proc(enc)
         enc.synchronize()
@@ -72,7 +80,8 @@ def main():
             b.record(enc)
             times.append(a.elapsed_ms(b))
         ms = med(times)
-        print(json.dumps({"what": "fft1m", "group": g, "streams": ns, "batch": args.batch, "ms": ms,
+        err = plan.get("device_error")
+        print(json.dumps({"what": "fft1m_" + kind, "a": g, "b": ns, "device_error": err, "batch": args.batch, "ms": ms,
                           "ms_all": times, "Gsamples_s": n * args.batch / (ms * 1e-3) / 1e9,
                           "roofline_frac": 16 * n * args.batch / (ms * 1e-3) / 8e12}), flush=True)
         plan.destroy()
