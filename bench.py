@@ -26,6 +26,18 @@ ALGO_BYTES_PER_SAMPLE = 16      # one 8-B read + one 8-B write p
 CHUNK = 8                       # steps between input regenerations (2^-40 * 2^(10*8) stays finite)
 
 
+def usable_cores():
+    """CPU share of this process: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +138,7 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
         cb = max(cores, 8)
         sps, reps = oracle.bench_forward(n, cb, threads=cores, min_seconds=args.cpu_seconds)
         cpu = {"value": sps / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": "port",
@@ -155,11 +167,12 @@ def main():
                                    f"{'; configs[3] shape' if world > 1 else ''})",
                        "fft_len": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective",
                        "plan_path": plan.get("path"), "group": plan.get("group"), "streams": plan.get("streams"),
+                       "mixed_launches": plan.get("mix"), "cache_policy": plan.get("policy"),
                        "launches_per_step": plan.get("launches_per_exec"),
                        "scratch_bytes": plan.get("scratch_bytes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "fwa_plan_exec (k_p1_1m + k_p2_1m pipeline)",
+                         "kernel": "k_mix_1m (every launch of one fwa_plan_exec; pass-1 + pass-2 tiles side by side)",
                          "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
                          "copy_ceiling_GBps_same_run": copy_gbps},

@@ -75,6 +75,9 @@ struct fwa_plan {
     uint32_t *fused_ctl = nullptr;
     int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
     int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
+    int64_t mix = 1;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
+    int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels.hip)
+    int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
@@ -158,7 +161,7 @@ int32_t build_pipeline(fwa_plan *p)
     const uint64_t n_groups = p->batch ? (p->batch + p->group - 1) / p->group : 0;
     if (p->n_streams < 1) p->n_streams = 1;
     if ((uint64_t)p->n_streams > n_groups && n_groups) p->n_streams = (int64_t)n_groups;
-    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams;
+    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams * (p->mix ? 2 : 1);
     if (p->ring_slots == 0) return FWA_OK;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->ring), p->ring_slots * (sizeof(v2f) << 20)));
     if (p->n_streams > 1) {
@@ -433,7 +436,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
 
     if (fft_len == 1) p->path = PATH_IDENTITY;
     else if (fft_len <= 4096) p->path = PATH_LDS_SMALL;
-    else if (fft_len == (1u << 20)) p->path = (p->batch < (1u << 24)) ? PATH_FUSED_1M : PATH_TWOPASS_1M;
+    else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;  // PATH_FUSED_1M is opt-in (experimental)
     else p->path = PATH_R2_GLOBAL;
 
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
@@ -538,31 +541,53 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             break;
         case PATH_FUSED_1M:
             // in place: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
-            e = fwa::launch_fused_1m(dir, a, plan->tw_inner, plan->tw_outer, plan->fused_ctl, (uint32_t)plan->batch,
-                                     (uint32_t)plan->depth, (uint32_t)plan->wgs, scale, st);
+            e = fwa::launch_fused_1m(dir, (int)plan->policy, a, plan->tw_inner, plan->tw_outer, plan->fused_ctl, (uint32_t)plan->batch,
+                                     (uint32_t)plan->depth, (uint32_t)plan->wgs, scale, (uint32_t)plan->dbg, st);
             break;
         case PATH_TWOPASS_1M: {
             const uint64_t G = (uint64_t)plan->group;
             const uint64_t n_groups = (plan->batch + G - 1) / G;
             const size_t ns = plan->istreams.size();
+            const size_t chains = ns ? ns : 1;
+            const uint64_t N = 1ull << 20;
             if (ns) {
                 HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
                 for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
             }
-            for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
-                const uint64_t t0 = g * G;
-                const uint32_t cnt = (uint32_t)((plan->batch - t0 < G) ? plan->batch - t0 : G);
-                const size_t si = ns ? (size_t)(g % ns) : 0;
-                hipStream_t s = ns ? plan->istreams[si] : st;
-                // ring region of this stream: slots [si*G, si*G + G); kernels index it by (t % ring_slots)
-                // through a per-launch base so that groups on different streams never share slots.
-                v2f *ring = plan->ring + (uint64_t)si * G * (1ull << 20);
-                // inside a group, transform t uses slot (t - t0): pass ring_slots = G and t_first offset
-                e = fwa::launch_p1_1m(dir, a + t0 * (1ull << 20), ring, plan->tw_inner, plan->tw_outer, (uint32_t)G, 0,
-                                      cnt, s);
-                if (e != hipSuccess) break;
-                e = fwa::launch_p2_1m(dir, ring, out + t0 * (1ull << 20), plan->tw_inner, (uint32_t)G, 0, cnt, scale,
-                                      s);
+            auto count = [&](uint64_t g) { return (uint32_t)((plan->batch - g * G < G) ? plan->batch - g * G : G); };
+            if (plan->mix) {
+                // chain c owns groups c, c+chains, ...; launch i of a chain = pass 1 of its i-th group next to
+                // pass 2 of its (i-1)-th group; two ring slabs per chain, used alternately.
+                const uint64_t rounds = (n_groups + chains - 1) / chains;
+                for (uint64_t i = 0; i <= rounds && e == hipSuccess; ++i) {
+                    for (size_t c = 0; c < chains && e == hipSuccess; ++c) {
+                        const uint64_t g = i * chains + c, gp = g - chains;  // gp valid when i > 0
+                        const bool has1 = (i < rounds) && g < n_groups;
+                        const bool has2 = (i > 0) && gp < n_groups;
+                        if (!has1 && !has2) continue;
+                        v2f *slab_w = plan->ring + ((uint64_t)c * 2 + (i & 1)) * G * N;
+                        v2f *slab_r = plan->ring + ((uint64_t)c * 2 + ((i + 1) & 1)) * G * N;
+                        e = fwa::launch_mix_1m(dir, (int)plan->policy, has1 ? a + g * G * N : a, slab_w,
+                                               has1 ? count(g) : 0, slab_r, has2 ? out + gp * G * N : out,
+                                               has2 ? count(gp) : 0, plan->tw_inner, plan->tw_outer, scale,
+                                               (uint32_t)plan->dbg,
+                                               ns ? plan->istreams[c] : st);
+                    }
+                }
+            } else {
+                for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
+                    const uint64_t t0 = g * G;
+                    const uint32_t cnt = count(g);
+                    const size_t si = ns ? (size_t)(g % ns) : 0;
+                    hipStream_t s = ns ? plan->istreams[si] : st;
+                    // ring region of this stream: G slots; inside a group transform t uses slot (t - t0)
+                    v2f *ring = plan->ring + (uint64_t)si * G * N;
+                    e = fwa::launch_p1_1m(dir, (int)plan->policy, a + t0 * N, ring, plan->tw_inner, plan->tw_outer,
+                                          (uint32_t)G, 0, cnt, s);
+                    if (e != hipSuccess) break;
+                    e = fwa::launch_p2_1m(dir, (int)plan->policy, ring, out + t0 * N, plan->tw_inner, (uint32_t)G, 0,
+                                          cnt, scale, s);
+                }
             }
             if (ns && e == hipSuccess) {
                 for (size_t i = 0; i < ns; ++i) {
@@ -590,6 +615,8 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "depth") *value = plan->depth;
     else if (k == "wgs") *value = plan->wgs;
+    else if (k == "policy") *value = plan->policy;
+    else if (k == "mix") *value = plan->mix;
     else if (k == "device_error") {
         // bounded-spin timeout flag of the fused kernel (0 in every healthy run); synchronises the device
         *value = 0;
@@ -606,7 +633,12 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
                  (plan->fused_ctl ? (int64_t)fwa::fused_ctl_bytes(plan->batch) : 0);
     else if (k == "launches_per_exec") {
         switch (plan->path) {
-            case PATH_TWOPASS_1M: *value = 2 * (int64_t)((plan->batch + plan->group - 1) / plan->group); break;
+            case PATH_TWOPASS_1M: {
+                const int64_t ng = (int64_t)((plan->batch + plan->group - 1) / plan->group);
+                const int64_t ch = plan->istreams.empty() ? 1 : (int64_t)plan->istreams.size();
+                *value = plan->mix ? ng + (ng < ch ? ng : ch) : 2 * ng;
+                break;
+            }
             case PATH_FUSED_1M: *value = 1; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
@@ -627,6 +659,17 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (k == "group") plan->group = value; else plan->n_streams = value;
         return build_pipeline(plan);
     }
+    if (k == "dbg") { plan->dbg = value; return FWA_OK; }
+    if (k == "mix") {
+        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 path");
+        plan->mix = value ? 1 : 0;
+        return build_pipeline(plan);
+    }
+    if (k == "policy") {
+        if (value < 0 || value > 4) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "policy out of range");
+        plan->policy = value;
+        return FWA_OK;
+    }
     if (k == "depth" || k == "wgs") {
         if (plan->path != PATH_FUSED_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the fused 2^20 path");
         if (value < 1 || value > 65536) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
@@ -635,6 +678,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     }
     if (k == "path") {
         if (plan->kind == FWA_NORMALIZE) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
+        if (value == PATH_FUSED_1M && plan->batch >= (1u << 24))
+            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "fused path needs batch < 2^24");
         if ((value == PATH_TWOPASS_1M || value == PATH_FUSED_1M) && plan->n == (1u << 20)) {
             plan->path = value;
             return build_pipeline(plan);

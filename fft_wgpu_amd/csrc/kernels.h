@@ -9,15 +9,21 @@ hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uin
 hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                             hipStream_t st);
 hipError_t setup_1m_kernels();
-hipError_t launch_p1_1m(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
+hipError_t launch_p1_1m(int dir, int policy, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                         uint32_t ring_slots, uint64_t t_first, uint32_t n_transforms, hipStream_t st);
-hipError_t launch_p2_1m(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t ring_slots,
+hipError_t launch_p2_1m(int dir, int policy, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t ring_slots,
                         uint64_t t_first, uint32_t n_transforms, float scale, hipStream_t st);
 size_t fused_ctl_bytes(uint64_t batch);
 // In-place persistent pipeline; `ctl` = fused_ctl_bytes(batch) bytes of device memory (zeroed here per call).
 // Needs >= 64 resident workgroups to be deadlock-free (see kernels.hip); batch*128 tickets must fit in u32.
-hipError_t launch_fused_1m(int dir, v2f *data, const v2f *tw_inner, const v2f *tw_outer, uint32_t *ctl,
-                           uint32_t batch, uint32_t depth, uint32_t n_workgroups, float scale, hipStream_t st);
+hipError_t launch_fused_1m(int dir, int policy, v2f *data, const v2f *tw_inner, const v2f *tw_outer, uint32_t *ctl,
+                           uint32_t batch, uint32_t depth, uint32_t n_workgroups, float scale, uint32_t dbg,
+                           hipStream_t st);
+// One launch = pass-1 tiles of n1 transforms (p1_src -> p1_ring) side by side with pass-2 tiles of n2
+// transforms (p2_ring -> p2_dst); the two sets are independent of each other.
+hipError_t launch_mix_1m(int dir, int policy, const v2f *p1_src, v2f *p1_ring, uint32_t n1, const v2f *p2_ring,
+                         v2f *p2_dst, uint32_t n2, const v2f *tw_inner, const v2f *tw_outer, float scale,
+                         uint32_t dbg, hipStream_t st);
 hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);

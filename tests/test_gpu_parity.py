@@ -39,7 +39,7 @@ def _check(oracle, y, r, n, tol=REL_TOL):
     return worst
 
 
-def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=None, wgs=None):
+def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=None, wgs=None, policy=None, mix=None):
     """reference call sequence (examples/basic.rs:73-122): write_buffer -> proc -> read back"""
     src = _upload(fw, dev, queue, x)
     src2 = dev.create_buffer(x.nbytes) if kind in ("Onlyinverse",) else None
@@ -56,6 +56,10 @@ def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=
         plan.set("depth", depth)
     if wgs is not None:
         plan.set("wgs", wgs)
+    if policy is not None:
+        plan.set("policy", policy)
+    if mix is not None:
+        plan.set("mix", mix)
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -156,17 +160,20 @@ def test_config_c1_n1024_batch1(gpu, oracle):
 
 
 # fused in-place pipeline (path 5, the default): (batch, depth, workgroups); two-launch ring (path 1): (batch, group, streams)
+# (two-launch ring is the default since the fused path's in-launch waits cost more than they save: DESIGN.md)
 @pytest.mark.parametrize("batch,path,a,b", [(1, 5, 4, 512), (3, 5, 1, 512), (5, 5, 2, 64), (17, 5, 4, 512),
                                             (40, 5, 6, 300), (9, 5, 16, 512),
-                                            (1, 1, 8, 2), (3, 1, 2, 2), (5, 1, 2, 1), (17, 1, 4, 3)])
+                                            (1, 1, 8, 2), (3, 1, 2, 2), (5, 1, 2, 1), (17, 1, 4, 3),
+                                            (1, 10, 8, 2), (3, 10, 2, 2), (5, 10, 2, 1), (17, 10, 4, 3), (23, 10, 3, 2)])
 def test_config_c2_n1m(gpu, oracle, batch, path, a, b):
     fw, dev, queue = gpu
     n = 1 << 20
     x = oracle.gen_input(n, batch)
-    kw = dict(depth=a, wgs=b) if path == 5 else dict(path=1, group=a, streams=b)
-    group, streams = a, b
+    # path 10 = two-launch ring without the mixed launches (mix=0); path 1 = mixed launches (default)
+    kw = (dict(path=5, depth=a, wgs=b) if path == 5 else
+          dict(path=1, group=a, streams=b, mix=1 if path == 1 else 0))
     y, which, plan = _run(fw, dev, queue, "Forward", x, n, **kw)
-    assert which == 0 and plan.get("path") == path
+    assert which == 0 and plan.get("path") == (5 if path == 5 else 1)
     r = oracle.dft_f64(x, n, -1)
     mx, l2 = _check(oracle, y, r, n)
     print("C2 batch %d: max_rel %.3g rel_l2 %.3g" % (batch, mx, l2))
@@ -180,16 +187,36 @@ def test_config_c2_n1m(gpu, oracle, batch, path, a, b):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4])
+def test_n1m_cache_policies_are_bit_identical(gpu, oracle, policy):
+    """Cache-policy variants (write-through / non-temporal accesses, with or without fences) change how
+    workgroups hand the intermediate over, never the arithmetic: every variant of both pipelines must
+    reproduce the default two-launch result bit for bit, also when the buffer is much larger than L2 and
+    execs run back to back (stale-line hazards show up as mismatching 128-byte lines)."""
+    fw, dev, queue = gpu
+    n, batch = 1 << 20, 96                      # 768 MiB: far beyond L2 (32 MiB) and Infinity Cache (256 MiB)
+    x = oracle.gen_input(n, batch, first_transform=5)
+    ref, _, _ = _run(fw, dev, queue, "Forward", x, n, path=1, policy=0)
+    mx, _ = oracle.compare(ref[:n], oracle.dft_f64(x[:n], n, -1))
+    assert mx <= REL_TOL
+    for kw in (dict(path=5, depth=4), dict(path=5, depth=2, wgs=200), dict(path=1, group=8, streams=2, mix=0),
+               dict(path=1, group=8, streams=2, mix=1), dict(path=1, group=5, streams=3, mix=1)):
+        for rep in range(2):
+            y, _, _ = _run(fw, dev, queue, "Forward", x, n, policy=policy, **kw)
+            bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
+            assert bad.size == 0, (policy, kw, rep, bad.size, bad[:8])
+
+
 def test_n1m_matches_literal_recurrence(gpu, oracle):
     fw, dev, queue = gpu
     n = 1 << 20
     x = oracle.gen_input(n, 2, first_transform=11)
     y_fast, _, _ = _run(fw, dev, queue, "Forward", x, n)
-    y_two, _, _ = _run(fw, dev, queue, "Forward", x, n, path=1)
+    y_two, _, _ = _run(fw, dev, queue, "Forward", x, n, path=5)
     y_lit, _, _ = _run(fw, dev, queue, "Forward", x, n, path=2)
     d = np.abs(y_fast.astype(np.complex128) - y_lit).max() / np.abs(y_lit).max()
     assert d <= REL_TOL, d
-    # fused in-place and two-launch pipelines run the same arithmetic: bit-identical
+    # fused in-place (path 5) and two-launch (default) pipelines run the same arithmetic: bit-identical
     assert np.array_equal(y_fast.view(np.uint32), y_two.view(np.uint32))
 
 

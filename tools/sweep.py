@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--settings", type=str, default="8x2", help="two-launch path: GROUPxSTREAMS,...")
+    ap.add_argument("--mix", type=str, default="", help="mixed-launch two-pass path: GROUPxSTREAMSxDBGxPOLICY,...")
     ap.add_argument("--fused", type=str, default="4x512,2x512,3x512,6x512,8x512,12x512,4x256,4x384",
                     help="fused path: DEPTHxWORKGROUPS,...")
     ap.add_argument("--copy", action="store_true")
@@ -58,17 +59,25 @@ def main():
         dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
         enc.synchronize()
 
-    runs = [("two", s) for s in args.settings.split(",") if s] + [("fused", s) for s in args.fused.split(",") if s]
+    runs = ([("two", s) for s in args.settings.split(",") if s] + [("mix", s) for s in args.mix.split(",") if s]
+            + [("fused", s) for s in args.fused.split(",") if s])
     for kind, s in runs:
-        g, ns = (int(v) for v in s.split("x"))
+        parts = [int(v) for v in s.split("x")]
+        g, ns = parts[0], parts[1]
+        dbg = parts[2] if len(parts) > 2 else 0
+        pol = parts[3] if len(parts) > 3 else 0
         plan = fw.Forward(dev, queue, buf, n)
-        if kind == "two":
+        if kind in ("two", "mix"):
             plan.set("path", 1)
+            plan.set("mix", 1 if kind == "mix" else 0)
             plan.set("group", g)
             plan.set("streams", ns)
         else:
             plan.set("depth", g)
             plan.set("wgs", ns)
+            if dbg:
+                plan.set("dbg", dbg)
+        plan.set("policy", pol)
         dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
         plan.proc(enc)
         enc.synchronize()
@@ -81,7 +90,7 @@ def main():
             times.append(a.elapsed_ms(b))
         ms = med(times)
         err = plan.get("device_error")
-        print(json.dumps({"what": "fft1m_" + kind, "a": g, "b": ns, "device_error": err, "batch": args.batch, "ms": ms,
+        print(json.dumps({"what": "fft1m_" + kind, "a": g, "b": ns, "dbg": dbg, "policy": pol, "device_error": err, "batch": args.batch, "ms": ms,
                           "ms_all": times, "Gsamples_s": n * args.batch / (ms * 1e-3) / 1e9,
                           "roofline_frac": 16 * n * args.batch / (ms * 1e-3) / 8e12}), flush=True)
         plan.destroy()
