@@ -58,3 +58,20 @@ def test_product_path_does_not_touch_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "ref_fft" not in text.replace(
                     "oracle/ref_fft.c", ""), f
+
+
+def test_cpp_mirror_compiles_against_the_header(tmp_path):
+    """include/fft_wgpu.hpp (the C++ host mirror) and the C++ replay of examples/basic_inverse2.rs build
+    against the C ABI; without a GPU the binary must fail with FWA_ERR_NO_DEVICE, not fall back."""
+    import subprocess
+    import torch
+    exe = tmp_path / "example"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "example_basic_inverse2.cpp"),
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+    else:
+        assert r.returncode == 2 and "error 5" in r.stderr

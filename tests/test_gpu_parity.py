@@ -340,3 +340,19 @@ def test_rejects_bad_arguments(gpu):
     assert p.get("batch") == 0
     enc = dev.create_command_encoder()
     assert p.proc(enc) is empty
+
+
+def test_cpp_mirror_replays_reference_example(gpu, tmp_path):
+    """include/fft_wgpu.hpp: C++ replay of examples/basic_inverse2.rs (Onlyinverse + Normalize, n=512,
+    constant input, max error < 1e-5) through the C ABI."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "example"
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "example_basic_inverse2.cpp"),
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "max error 0" in r.stdout
