@@ -48,6 +48,7 @@ enum fwa_path : int64_t {
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,
     PATH_FUSED_1M = 5,  // in-place persistent pipeline, one launch per exec
+    PATH_SPLIT = 6,     // n = R1*R2*M: strided register-radix passes + fast sub-transforms (M = 2^20 or 4096) + permute
 };
 
 struct fwa_plan {
@@ -66,6 +67,10 @@ struct fwa_plan {
     v2f *tw_half = nullptr;        // n/2 entries, processor.rs:43-49
     v2f *tw_inner = nullptr;       // 2^20 path: [k1][n'] = W_1024^{n' k1}
     v2f *tw_outer = nullptr;       // 2^20 path: per tile A[32][16], B[32][16]
+    // split path (PATH_SPLIT)
+    uint32_t r1 = 1, r2 = 1, leaf = 0;  // n = r1 * r2 * leaf
+    v2f *tw_lo1 = nullptr, *tw_hi1 = nullptr, *tw_lo2 = nullptr, *tw_hi2 = nullptr;
+    uint64_t leaf_batch = 0;            // sub-transforms the 2^20 pipeline / LDS kernel runs per exec
     // 2^20 pipeline
     v2f *ring = nullptr;
     int64_t group = 8;             // transforms per launch pair
@@ -149,16 +154,17 @@ int32_t build_pipeline(fwa_plan *p)
 {
     fwa_ctx *ctx = p->ctx;
     release_pipeline(p);
+    const uint64_t pbatch = p->leaf_batch;
     if (p->path == PATH_FUSED_1M) {
-        if (p->batch == 0) return FWA_OK;
+        if (pbatch == 0) return FWA_OK;
         if (p->wgs <= 0) p->wgs = 2 * (int64_t)ctx->prop.multiProcessorCount;
         if (p->wgs < 64) p->wgs = 64;  // progress guarantee of k_fused_1m needs >= 64 resident workgroups
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->fused_ctl), fwa::fused_ctl_bytes(p->batch)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->fused_ctl), fwa::fused_ctl_bytes(pbatch)));
         return FWA_OK;
     }
     if (p->group < 1) p->group = 1;
-    if ((uint64_t)p->group > p->batch && p->batch) p->group = (int64_t)p->batch;
-    const uint64_t n_groups = p->batch ? (p->batch + p->group - 1) / p->group : 0;
+    if ((uint64_t)p->group > pbatch && pbatch) p->group = (int64_t)pbatch;
+    const uint64_t n_groups = pbatch ? (pbatch + p->group - 1) / p->group : 0;
     if (p->n_streams < 1) p->n_streams = 1;
     if ((uint64_t)p->n_streams > n_groups && n_groups) p->n_streams = (int64_t)n_groups;
     p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams * (p->mix ? 2 : 1);
@@ -390,6 +396,8 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
     if (plan->tw_half) (void)hipFree(plan->tw_half);
     if (plan->tw_inner) (void)hipFree(plan->tw_inner);
     if (plan->tw_outer) (void)hipFree(plan->tw_outer);
+    for (v2f *t : {plan->tw_lo1, plan->tw_hi1, plan->tw_lo2, plan->tw_hi2})
+        if (t) (void)hipFree(t);
     if (plan->second_owned && plan->own_second.p) (void)hipFree(plan->own_second.p);
     delete plan;
     return FWA_OK;
@@ -437,12 +445,21 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     if (fft_len == 1) p->path = PATH_IDENTITY;
     else if (fft_len <= 4096) p->path = PATH_LDS_SMALL;
     else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;  // PATH_FUSED_1M is opt-in (experimental)
+    else if (fft_len >= (1u << 13) && fft_len <= (1u << 30)) p->path = PATH_SPLIT;
     else p->path = PATH_R2_GLOBAL;
+    p->leaf_batch = p->batch;
+    if (p->path == PATH_SPLIT) {
+        p->leaf = (fft_len > (1u << 20)) ? (1u << 20) : 4096u;
+        const uint32_t rt = fft_len / p->leaf;
+        p->r1 = rt <= 32 ? rt : 32;
+        p->r2 = rt / p->r1;
+        p->leaf_batch = p->batch * rt;
+    }
 
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
     // materialised when the result must land there (odd log2 n) or the path ping-pongs.
     const bool odd = (p->lg & 1) != 0;
-    const bool need_second = odd || p->path == PATH_R2_GLOBAL;
+    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT;
     if (!p->second && need_second && src->bytes) {
         hipError_t e = hipMalloc(&p->own_second.p, src->bytes);
         if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipMalloc(second buffer)"));
@@ -456,12 +473,29 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         p->second = &p->own_second;
     }
 
-    if (p->path == PATH_LDS_SMALL || p->path == PATH_R2_GLOBAL) {
-        std::vector<v2f> h(fft_len / 2);
-        for (uint32_t k = 0; k < fft_len / 2; ++k) h[k] = tw_f64(k, fft_len);
+    if (p->path == PATH_SPLIT) {
+        auto level = [&](uint64_t cur, v2f **lo, v2f **hi) -> int32_t {
+            const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
+            std::vector<v2f> l(nlo), h(nhi);
+            for (uint64_t j = 0; j < nlo; ++j) l[j] = tw_f64(j, cur);
+            for (uint64_t j = 0; j < nhi; ++j) h[j] = tw_f64(1024 * j, cur);
+            int32_t s = upload_table(ctx, l, lo);
+            return s ? s : upload_table(ctx, h, hi);
+        };
+        st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
+        if (st) return bail(st);
+        if (p->r2 > 1) {
+            st = level(fft_len / p->r1, &p->tw_lo2, &p->tw_hi2);
+            if (st) return bail(st);
+        }
+    }
+    const uint32_t leaf_n = (p->path == PATH_SPLIT) ? p->leaf : fft_len;
+    if (p->path == PATH_LDS_SMALL || p->path == PATH_R2_GLOBAL || (p->path == PATH_SPLIT && leaf_n == 4096)) {
+        std::vector<v2f> h(leaf_n / 2);
+        for (uint32_t k = 0; k < leaf_n / 2; ++k) h[k] = tw_f64(k, leaf_n);
         st = upload_table(ctx, h, &p->tw_half);
         if (st) return bail(st);
-    } else if (p->path == PATH_TWOPASS_1M || p->path == PATH_FUSED_1M) {
+    } else if (p->path == PATH_TWOPASS_1M || p->path == PATH_FUSED_1M || p->path == PATH_SPLIT) {
         if (!ctx->setup_1m_done) {
             hipError_t e = fwa::setup_1m_kernels();
             if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
@@ -493,6 +527,63 @@ static fwa_buf *result_buffer(fwa_plan *p)
 {
     // processor.rs:153-157, :335-339, :664-668
     return (p->lg % 2 == 0) ? p->src : p->second;
+}
+
+// The 2^20 two-pass pipeline on `nb` transforms starting at `a` (results to `out`, may alias `a`).
+static int32_t exec_twopass(fwa_plan *plan, int dir, v2f *a, v2f *out, uint64_t nb, float scale, hipStream_t st)
+{
+    fwa_ctx *ctx = plan->ctx;
+    hipError_t e = hipSuccess;
+    const uint64_t G = (uint64_t)plan->group;
+    const uint64_t n_groups = (nb + G - 1) / G;
+    const size_t ns = plan->istreams.size();
+    const size_t chains = ns ? ns : 1;
+    const uint64_t N = 1ull << 20;
+    if (ns) {
+        HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
+        for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
+    }
+    auto count = [&](uint64_t g) { return (uint32_t)((nb - g * G < G) ? nb - g * G : G); };
+    if (plan->mix) {
+        // chain c owns groups c, c+chains, ...; launch i of a chain = pass 1 of its i-th group next to
+        // pass 2 of its (i-1)-th group; two ring slabs per chain, used alternately.
+        const uint64_t rounds = (n_groups + chains - 1) / chains;
+        for (uint64_t i = 0; i <= rounds && e == hipSuccess; ++i) {
+            for (size_t c = 0; c < chains && e == hipSuccess; ++c) {
+                const uint64_t g = i * chains + c, gp = g - chains;  // gp valid when i > 0
+                const bool has1 = (i < rounds) && g < n_groups;
+                const bool has2 = (i > 0) && gp < n_groups;
+                if (!has1 && !has2) continue;
+                v2f *slab_w = plan->ring + ((uint64_t)c * 2 + (i & 1)) * G * N;
+                v2f *slab_r = plan->ring + ((uint64_t)c * 2 + ((i + 1) & 1)) * G * N;
+                e = fwa::launch_mix_1m(dir, (int)plan->policy, has1 ? a + g * G * N : a, slab_w, has1 ? count(g) : 0,
+                                       slab_r, has2 ? out + gp * G * N : out, has2 ? count(gp) : 0, plan->tw_inner,
+                                       plan->tw_outer, scale, (uint32_t)plan->dbg, ns ? plan->istreams[c] : st);
+            }
+        }
+    } else {
+        for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
+            const uint64_t t0 = g * G;
+            const uint32_t cnt = count(g);
+            const size_t si = ns ? (size_t)(g % ns) : 0;
+            hipStream_t s = ns ? plan->istreams[si] : st;
+            // ring region of this stream: G slots; inside a group transform t uses slot (t - t0)
+            v2f *ring = plan->ring + (uint64_t)si * G * N;
+            e = fwa::launch_p1_1m(dir, (int)plan->policy, a + t0 * N, ring, plan->tw_inner, plan->tw_outer, (uint32_t)G,
+                                  0, cnt, s);
+            if (e != hipSuccess) break;
+            e = fwa::launch_p2_1m(dir, (int)plan->policy, ring, out + t0 * N, plan->tw_inner, (uint32_t)G, 0, cnt, scale,
+                                  s);
+        }
+    }
+    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
+    if (ns) {
+        for (size_t i = 0; i < ns; ++i) {
+            HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
+        }
+    }
+    return FWA_OK;
 }
 
 int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
@@ -545,56 +636,29 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                                      (uint32_t)plan->depth, (uint32_t)plan->wgs, scale, (uint32_t)plan->dbg, st);
             break;
         case PATH_TWOPASS_1M: {
-            const uint64_t G = (uint64_t)plan->group;
-            const uint64_t n_groups = (plan->batch + G - 1) / G;
-            const size_t ns = plan->istreams.size();
-            const size_t chains = ns ? ns : 1;
-            const uint64_t N = 1ull << 20;
-            if (ns) {
-                HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
-                for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
-            }
-            auto count = [&](uint64_t g) { return (uint32_t)((plan->batch - g * G < G) ? plan->batch - g * G : G); };
-            if (plan->mix) {
-                // chain c owns groups c, c+chains, ...; launch i of a chain = pass 1 of its i-th group next to
-                // pass 2 of its (i-1)-th group; two ring slabs per chain, used alternately.
-                const uint64_t rounds = (n_groups + chains - 1) / chains;
-                for (uint64_t i = 0; i <= rounds && e == hipSuccess; ++i) {
-                    for (size_t c = 0; c < chains && e == hipSuccess; ++c) {
-                        const uint64_t g = i * chains + c, gp = g - chains;  // gp valid when i > 0
-                        const bool has1 = (i < rounds) && g < n_groups;
-                        const bool has2 = (i > 0) && gp < n_groups;
-                        if (!has1 && !has2) continue;
-                        v2f *slab_w = plan->ring + ((uint64_t)c * 2 + (i & 1)) * G * N;
-                        v2f *slab_r = plan->ring + ((uint64_t)c * 2 + ((i + 1) & 1)) * G * N;
-                        e = fwa::launch_mix_1m(dir, (int)plan->policy, has1 ? a + g * G * N : a, slab_w,
-                                               has1 ? count(g) : 0, slab_r, has2 ? out + gp * G * N : out,
-                                               has2 ? count(gp) : 0, plan->tw_inner, plan->tw_outer, scale,
-                                               (uint32_t)plan->dbg,
-                                               ns ? plan->istreams[c] : st);
-                    }
-                }
+            const int32_t s2 = exec_twopass(plan, dir, a, out, plan->batch, scale, st);
+            if (s2) return s2;
+            break;
+        }
+        case PATH_SPLIT: {
+            // even log2 n: src -> second (pass 1), work in second, permute back into src; odd: work in src,
+            // permute into second -- the result lands where processor.rs:153-157 says.
+            const uint32_t lg_m = ilog2(plan->leaf), lg_r1 = ilog2(plan->r1), lg_r2 = ilog2(plan->r2);
+            v2f *work = (plan->lg % 2 == 0) ? b : a;
+            e = fwa::launch_radix_pass(dir, (int)plan->r1, a, work, plan->tw_lo1, plan->tw_hi1, lg_m + lg_r2,
+                                       plan->batch, st);
+            if (e == hipSuccess && plan->r2 > 1)
+                e = fwa::launch_radix_pass(dir, (int)plan->r2, work, work, plan->tw_lo2, plan->tw_hi2, lg_m,
+                                           plan->batch * plan->r1, st);
+            if (e != hipSuccess) break;
+            if (plan->leaf == (1u << 20)) {
+                const int32_t s2 = exec_twopass(plan, dir, work, work, plan->leaf_batch, 1.0f, st);
+                if (s2) return s2;
             } else {
-                for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
-                    const uint64_t t0 = g * G;
-                    const uint32_t cnt = count(g);
-                    const size_t si = ns ? (size_t)(g % ns) : 0;
-                    hipStream_t s = ns ? plan->istreams[si] : st;
-                    // ring region of this stream: G slots; inside a group transform t uses slot (t - t0)
-                    v2f *ring = plan->ring + (uint64_t)si * G * N;
-                    e = fwa::launch_p1_1m(dir, (int)plan->policy, a + t0 * N, ring, plan->tw_inner, plan->tw_outer,
-                                          (uint32_t)G, 0, cnt, s);
-                    if (e != hipSuccess) break;
-                    e = fwa::launch_p2_1m(dir, (int)plan->policy, ring, out + t0 * N, plan->tw_inner, (uint32_t)G, 0,
-                                          cnt, scale, s);
-                }
+                e = fwa::launch_lds_small(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st);
+                if (e != hipSuccess) break;
             }
-            if (ns && e == hipSuccess) {
-                for (size_t i = 0; i < ns; ++i) {
-                    HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
-                    HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
-                }
-            }
+            e = fwa::launch_permute(work, out, lg_r1, lg_r2, lg_m, plan->batch, scale, st);
             break;
         }
         default:
@@ -640,6 +704,16 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
                 break;
             }
             case PATH_FUSED_1M: *value = 1; break;
+            case PATH_SPLIT: {
+                int64_t leafl = 1;
+                if (plan->leaf == (1u << 20)) {
+                    const int64_t ng = (int64_t)((plan->leaf_batch + plan->group - 1) / plan->group);
+                    const int64_t ch = plan->istreams.empty() ? 1 : (int64_t)plan->istreams.size();
+                    leafl = plan->mix ? ng + (ng < ch ? ng : ch) : 2 * ng;
+                }
+                *value = 1 + (plan->r2 > 1 ? 1 : 0) + leafl + 1;
+                break;
+            }
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
             default: *value = 1;
@@ -654,7 +728,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (plan->frozen) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "plan tunables are locked after the first exec");
     const std::string k(key);
     if (k == "group" || k == "streams") {
-        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 path");
+        if (plan->path != PATH_TWOPASS_1M && !(plan->path == PATH_SPLIT && plan->leaf == (1u << 20)))
+            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 pipeline");
         if (value < 1 || value > 4096) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
         if (k == "group") plan->group = value; else plan->n_streams = value;
         return build_pipeline(plan);

@@ -24,6 +24,13 @@ hipError_t launch_fused_1m(int dir, int policy, v2f *data, const v2f *tw_inner, 
 hipError_t launch_mix_1m(int dir, int policy, const v2f *p1_src, v2f *p1_ring, uint32_t n1, const v2f *p2_ring,
                          v2f *p2_dst, uint32_t n2, const v2f *tw_inner, const v2f *tw_outer, float scale,
                          uint32_t dbg, hipStream_t st);
+// n = R * S split: radix-R butterflies over stride S with twiddle W_(R*S)^{n2 k1} = hi[e>>10]*lo[e&1023]; `n_sub`
+// independent arrays of length R*S; in == out allowed (each thread owns its R positions).
+hipError_t launch_radix_pass(int dir, int R, const v2f *in, v2f *out, const v2f *tw_lo, const v2f *tw_hi,
+                             uint32_t lg_s, uint64_t n_sub, hipStream_t st);
+// digit-reversal permute of `batch` transforms of length R1*R2*M (out of place).
+hipError_t launch_permute(const v2f *in, v2f *out, uint32_t lg_r1, uint32_t lg_r2, uint32_t lg_m, uint64_t batch,
+                          float scale, hipStream_t st);
 hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);

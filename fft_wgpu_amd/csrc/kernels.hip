@@ -633,6 +633,103 @@ hipError_t launch_p2_1m(int dir, int policy, const v2f *ring, v2f *dst, const v2
 }
 
 // ---------------------------------------------------------------------------
+// Large / mid-size transforms: n = R1 * R2 * M.  Strided register-radix passes split the transform into
+// R1*R2 contiguous sub-transforms of length M (M = 2^20 -> the two-pass pipeline above, M = 4096 ->
+// k_lds_small), and one digit-reversal permute restores natural order:
+//   X[k1 + R*k'] = DFT_S(sub-array k1)[k'],  sub-array k1 [n2] = W_cur^{n2 k1} * sum_{n1} x[n1*S + n2] W_R^{n1 k1}
+// (cur = R*S).  This replaces the reference's log2(n) full passes (fft4.wgsl:36-101) by 2-3 passes plus
+// the sub-transform.  Twiddle W_cur^e = hi[e >> 10] * lo[e & 1023] (two f64-derived table entries).
+// ---------------------------------------------------------------------------
+template <int R, int DIR>
+__global__ __launch_bounds__(256) void k_radix_pass(const v2f *__restrict__ in, v2f *__restrict__ out,
+                                                    const v2f *__restrict__ tw_lo, const v2f *__restrict__ tw_hi,
+                                                    uint32_t lg_s, uint64_t total /* n_sub * S */)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const uint32_t S = 1u << lg_s;
+    const uint64_t sub = g >> lg_s;
+    const uint32_t n2 = (uint32_t)(g & (S - 1));
+    const uint64_t base = sub * ((uint64_t)R << lg_s) + n2;
+    v2f x[R];
+    static_for<0, R>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        x[j] = in[base + ((uint64_t)j << lg_s)];
+    });
+    fft_reg<R, DIR>(x);
+    static_for<0, R>([&](auto k_) {
+        constexpr int k1 = decltype(k_)::value;
+        v2f v = x[brev<R>(k1)];
+        if constexpr (k1 != 0) {
+            const uint32_t e = n2 * (uint32_t)k1;  // < cur <= 2^30
+            const v2f w = cmul(tw_hi[e >> 10], tw_lo[e & 1023]);
+            v = cmul_tw<DIR>(v, w);
+        }
+        out[base + ((uint64_t)k1 << lg_s)] = v;
+    });
+}
+
+template <int DIR>
+static hipError_t launch_radix_pass_dir(int R, const v2f *in, v2f *out, const v2f *lo, const v2f *hi, uint32_t lg_s,
+                                        uint64_t total, hipStream_t st)
+{
+    const uint64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 g((uint32_t)blocks), b(256);
+    switch (R) {
+        case 2: hipLaunchKernelGGL((k_radix_pass<2, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
+        case 4: hipLaunchKernelGGL((k_radix_pass<4, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
+        case 8: hipLaunchKernelGGL((k_radix_pass<8, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
+        case 16: hipLaunchKernelGGL((k_radix_pass<16, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
+        case 32: hipLaunchKernelGGL((k_radix_pass<32, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_radix_pass(int dir, int R, const v2f *in, v2f *out, const v2f *tw_lo, const v2f *tw_hi,
+                             uint32_t lg_s, uint64_t n_sub, hipStream_t st)
+{
+    const uint64_t total = n_sub << lg_s;
+    if (total == 0) return hipSuccess;
+    return dir == FWD ? launch_radix_pass_dir<FWD>(R, in, out, tw_lo, tw_hi, lg_s, total, st)
+                      : launch_radix_pass_dir<INV>(R, in, out, tw_lo, tw_hi, lg_s, total, st);
+}
+
+// out[t][k1 + R1*(k2 + R2*k3)] = scale * in[t][(k1*R2 + k2)*M + k3]; one thread per (t, k3), reads coalesced
+// over k3, each thread writes Rt = R1*R2 consecutive outputs.
+__global__ __launch_bounds__(256) void k_permute(const v2f *__restrict__ in, v2f *__restrict__ out, uint32_t lg_r1,
+                                                 uint32_t lg_r2, uint32_t lg_m, uint64_t total /* batch * M */,
+                                                 float scale)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const uint32_t lg_rt = lg_r1 + lg_r2;
+    const uint64_t t = g >> lg_m;
+    const uint32_t k3 = (uint32_t)(g & ((1u << lg_m) - 1));
+    const v2f *src = in + (t << (lg_m + lg_rt)) + k3;
+    v2f *dst = out + (t << (lg_m + lg_rt)) + ((uint64_t)k3 << lg_rt);
+    const uint32_t Rt = 1u << lg_rt, R1m = (1u << lg_r1) - 1;
+    for (uint32_t q = 0; q < Rt; q += 2) {  // q = k1 + R1*k2 ; Rt >= 2
+        const uint32_t qa = q, qb = q + 1;
+        const v2f a = src[(uint64_t)(((qa & R1m) << lg_r2) + (qa >> lg_r1)) << lg_m] * scale;
+        const v2f b = src[(uint64_t)(((qb & R1m) << lg_r2) + (qb >> lg_r1)) << lg_m] * scale;
+        *reinterpret_cast<v4f *>(dst + q) = v4f{a.x, a.y, b.x, b.y};
+    }
+}
+
+hipError_t launch_permute(const v2f *in, v2f *out, uint32_t lg_r1, uint32_t lg_r2, uint32_t lg_m, uint64_t batch,
+                          float scale, hipStream_t st)
+{
+    const uint64_t total = batch << lg_m;
+    if (total == 0) return hipSuccess;
+    const uint64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_permute, dim3((uint32_t)blocks), dim3(256), 0, st, in, out, lg_r1, lg_r2, lg_m, total, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // elementwise: normalize (normalize.wgsl:9-12), synthetic fill, calibration copy
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scale(const v4f *a, v4f *b, uint64_t n_vec,

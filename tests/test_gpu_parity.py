@@ -134,7 +134,8 @@ def test_literal_recurrence_matches_restatement_bitwise_shape(gpu, oracle):
 
 # ---- size sweep incl. ragged batches, 64-bit-free small cases ----
 @pytest.mark.parametrize("lg,batch", [(0, 5), (1, 7), (2, 1), (3, 1000), (4, 1), (5, 33), (6, 129), (9, 2500),
-                                      (10, 1), (11, 5), (12, 3), (13, 2), (14, 3), (16, 2), (18, 1), (19, 1)])
+                                      (10, 1), (11, 5), (12, 3), (13, 2), (14, 3), (15, 3), (16, 2), (17, 5), (18, 1),
+                                      (19, 3), (21, 1), (22, 3), (23, 1)])
 def test_size_sweep(gpu, oracle, lg, batch):
     fw, dev, queue = gpu
     n = 1 << lg
@@ -224,8 +225,8 @@ def test_config_c5_n16m_batch1(gpu, oracle):
     fw, dev, queue = gpu
     n = 1 << 24
     x = oracle.gen_input(n, 1)
-    y, which, _ = _run(fw, dev, queue, "Forward", x, n)
-    assert which == 0
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n)
+    assert which == 0 and plan.get("path") == 6  # split: radix-16 pass + 16 x 2^20 pipeline + permute
     mx, l2 = _check(oracle, y, oracle.dft_f64(x, n, -1), n)
     print("C5 max_rel %.3g rel_l2 %.3g" % (mx, l2))
 
