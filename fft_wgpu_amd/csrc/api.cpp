@@ -24,6 +24,7 @@ struct fwa_ctx {
     hipDeviceProp_t prop{};
     mutable std::string err;
     bool setup_1m_done = false;
+    bool setup_small_done = false;
 };
 struct fwa_stream {
     fwa_ctx *ctx = nullptr;
@@ -80,6 +81,7 @@ struct fwa_plan {
     uint32_t *fused_ctl = nullptr;
     int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
     int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
+    int64_t small_reg = 1;         // n in [16, 4096]: 1 = register radix-16 kernel, 0 = LDS radix-2 kernel
     int64_t mix = 1;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
     int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels.hip)
     int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
@@ -443,9 +445,9 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     }
 
     if (fft_len == 1) p->path = PATH_IDENTITY;
-    else if (fft_len <= 4096) p->path = PATH_LDS_SMALL;
+    else if (fft_len <= 16384) p->path = PATH_LDS_SMALL;
     else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;  // PATH_FUSED_1M is opt-in (experimental)
-    else if (fft_len >= (1u << 13) && fft_len <= (1u << 30)) p->path = PATH_SPLIT;
+    else if (fft_len >= (1u << 15) && fft_len <= (1u << 30)) p->path = PATH_SPLIT;
     else p->path = PATH_R2_GLOBAL;
     p->leaf_batch = p->batch;
     if (p->path == PATH_SPLIT) {
@@ -473,6 +475,11 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         p->second = &p->own_second;
     }
 
+    if (p->path == PATH_LDS_SMALL && fft_len > 4096 && !ctx->setup_small_done) {
+        hipError_t e = fwa::setup_small_kernels();
+        if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
+        ctx->setup_small_done = true;
+    }
     if (p->path == PATH_SPLIT) {
         auto level = [&](uint64_t cur, v2f **lo, v2f **hi) -> int32_t {
             const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
@@ -620,7 +627,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
             break;
         case PATH_LDS_SMALL:
-            e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
+            if (plan->small_reg && plan->n >= 16)
+                e = fwa::launch_small16(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
+            else
+                e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
             break;
         case PATH_R2_GLOBAL:
             for (uint32_t s = 0; s < plan->lg && e == hipSuccess; ++s) {
@@ -655,7 +665,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 const int32_t s2 = exec_twopass(plan, dir, work, work, plan->leaf_batch, 1.0f, st);
                 if (s2) return s2;
             } else {
-                e = fwa::launch_lds_small(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st);
+                e = plan->small_reg
+                        ? fwa::launch_small16(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st)
+                        : fwa::launch_lds_small(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st);
                 if (e != hipSuccess) break;
             }
             e = fwa::launch_permute(work, out, lg_r1, lg_r2, lg_m, plan->batch, scale, st);
@@ -681,6 +693,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "wgs") *value = plan->wgs;
     else if (k == "policy") *value = plan->policy;
     else if (k == "mix") *value = plan->mix;
+    else if (k == "small_reg") *value = plan->small_reg;
     else if (k == "device_error") {
         // bounded-spin timeout flag of the fused kernel (0 in every healthy run); synchronises the device
         *value = 0;
@@ -735,6 +748,11 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         return build_pipeline(plan);
     }
     if (k == "dbg") { plan->dbg = value; return FWA_OK; }
+    if (k == "small_reg") {
+        if (!value && plan->n > 4096) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
+        plan->small_reg = value ? 1 : 0;
+        return FWA_OK;
+    }
     if (k == "mix") {
         if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 path");
         plan->mix = value ? 1 : 0;

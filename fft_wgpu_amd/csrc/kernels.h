@@ -8,6 +8,11 @@ hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uin
                            uint64_t batch, float scale, hipStream_t st);
 hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                             hipStream_t st);
+// 16 <= n <= 16384: register radix-16 Stockham (one launch); src == dst allowed (a transform is read
+// completely before any of it is written)
+hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                          hipStream_t st);
+hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();
 hipError_t launch_p1_1m(int dir, int policy, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                         uint32_t ring_slots, uint64_t t_first, uint32_t n_transforms, hipStream_t st);

@@ -121,6 +121,145 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 }
 
 // ---------------------------------------------------------------------------
+// small transforms, 16 <= n <= 4096: register radix-16 Stockham.  Each thread owns 16 points; a transform
+// uses n/16 threads; stages are radix 16, 16, ... and a last stage of radix n / 16^k (2, 4 or 8 -- the
+// thread then does 16/R butterflies).  Stage recurrence = the reference's (fft.wgsl:27-62) with the pair
+// (a, b) generalised to R inputs:  idx = s*J + j;  inputs idx + m*n/R;  outputs s*R*J + j + q*J, scaled
+// by W_n^{s*J*q} (table of processor.rs:43-49).  The first stage reads global memory directly (coalesced
+// over idx), the last one writes it directly (coalesced over idx); in between one LDS buffer, padded by
+// one element per 16, carries the exchange (conflict-free b64 writes at every stage).
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ v2f tw_lookup(const v2f *__restrict__ tw, uint32_t e)  // W_N^e, 0 <= e < N
+{
+    const v2f w = tw[e & (N / 2 - 1)];
+    return (e & (N / 2)) ? -w : w;
+}
+
+template <int R, int N, int DIR, class Get, class Put>
+__device__ __forceinline__ void stage_bfly(Get get, Put put, const v2f *__restrict__ tw, uint32_t idx, uint32_t J)
+{
+    // one radix-R butterfly of the Stockham stage with sub-block size J
+    v2f x[R];
+    static_for<0, R>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = get(idx + m * (N / R)); });
+    fft_reg<R, DIR>(x);
+    const uint32_t j = idx & (J - 1);
+    const uint32_t sJ = idx - j;  // s*J
+    static_for<0, R>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        v2f v = x[brev<R>(q)];
+        if constexpr (q != 0) {
+            if (J * R < N) v = cmul_tw<DIR>(v, tw_lookup<N>(tw, sJ * q));  // last stage: s = 0, no twiddle
+        }
+        put(sJ * R + j + q * J, v);
+    });
+}
+
+template <int LGN, int DIR>
+__global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small16(const v2f *__restrict__ src,
+                                                                                  v2f *__restrict__ dst,
+                                                                                  const v2f *__restrict__ tw,
+                                                                                  uint64_t batch, float scale)
+{
+    constexpr int N = 1 << LGN;
+    constexpr int TPX = N / 16;                       // threads per transform
+    constexpr int WG = LGN <= 12 ? 256 : TPX;         // 8192 / 16384 points: one transform per 512 / 1024 threads
+    constexpr int XPW = WG / TPX;                     // transforms per workgroup
+    constexpr int NS16 = LGN / 4;        // radix-16 stages
+    constexpr int RL = 1 << (LGN % 4);   // last radix (1 = none)
+    constexpr int PADN = N + N / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f *lds = reinterpret_cast<v2f *>(smem) + (threadIdx.x / TPX) * PADN;
+    const uint32_t t = threadIdx.x % TPX;
+    const uint64_t xf = (uint64_t)blockIdx.x * XPW + threadIdx.x / TPX;
+    const bool live = xf < batch;
+    const v2f *g_in = src + xf * N;
+    v2f *g_out = dst + xf * N;
+    auto pad = [](uint32_t p) { return p + (p >> 4); };
+
+    // stage 0: global -> (LDS | global)
+    {
+        constexpr bool only = (NS16 == 1 && RL == 1);
+        if (live || !only)
+            stage_bfly<16, N, DIR>([&](uint32_t i) { return live ? g_in[i] : v2f{0.f, 0.f}; },
+                                   [&](uint32_t o, v2f v) {
+                                       if constexpr (only) { if (live) g_out[o] = v * scale; }
+                                       else lds[pad(o)] = v;
+                                   },
+                                   tw, t, 1u);
+        if constexpr (only) return;
+    }
+    uint32_t J = 16;
+    // middle radix-16 stages
+    static_for<1, NS16>([&](auto s_) {
+        constexpr int st = decltype(s_)::value;
+        constexpr bool last = (st == NS16 - 1) && RL == 1;
+        __syncthreads();
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * (N / 16))]; });
+        if constexpr (!last) __syncthreads();
+        fft_reg<16, DIR>(x);
+        const uint32_t j = t & (J - 1), sJ = t - j;
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            v2f v = x[brev<16>(q)];
+            if constexpr (q != 0 && !last) v = cmul_tw<DIR>(v, tw_lookup<N>(tw, sJ * q));
+            const uint32_t o = sJ * 16 + j + q * J;
+            if constexpr (last) { if (live) g_out[o] = v * scale; }
+            else lds[pad(o)] = v;
+        });
+        J *= 16;
+    });
+    // last stage of radix RL < 16: 16/RL butterflies per thread, outputs straight to global
+    if constexpr (RL > 1) {
+        __syncthreads();
+        static_for<0, 16 / RL>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            stage_bfly<RL, N, DIR>([&](uint32_t i) { return lds[pad(i)]; },
+                                   [&](uint32_t o, v2f v) { if (live) g_out[o] = v * scale; }, tw, t + b * TPX, J);
+        });
+    }
+}
+
+template <int DIR>
+static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t batch, float scale,
+                                     hipStream_t st)
+{
+    const uint32_t n = 1u << lg_n;
+    const uint32_t wg = lg_n <= 12 ? 256 : n / 16;
+    const uint32_t xpw = wg / (n / 16);
+    const uint64_t blocks = (batch + xpw - 1) / xpw;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (lg_n == 4) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
+    const dim3 g((uint32_t)blocks), b(wg);
+    switch (lg_n) {
+        case 4: hipLaunchKernelGGL((k_small16<4, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 5: hipLaunchKernelGGL((k_small16<5, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 6: hipLaunchKernelGGL((k_small16<6, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 7: hipLaunchKernelGGL((k_small16<7, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 8: hipLaunchKernelGGL((k_small16<8, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 9: hipLaunchKernelGGL((k_small16<9, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 10: hipLaunchKernelGGL((k_small16<10, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 11: hipLaunchKernelGGL((k_small16<11, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 12: hipLaunchKernelGGL((k_small16<12, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 13: hipLaunchKernelGGL((k_small16<13, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 14: hipLaunchKernelGGL((k_small16<14, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                          hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    uint32_t lg_n = 0;
+    while ((1u << lg_n) < n) ++lg_n;
+    return dir == FWD ? launch_small16_dir<FWD>(src, dst, tw, lg_n, batch, scale, st)
+                      : launch_small16_dir<INV>(src, dst, tw, lg_n, batch, scale, st);
+}
+
+// ---------------------------------------------------------------------------
 // n = 2^20 = 1024 x 1024, two passes.
 //
 // Index algebra (n = 1024*n1 + n2, k = K1 + 1024*K2):
@@ -578,6 +717,19 @@ hipError_t launch_mix_1m(int dir, int policy, const v2f *p1_src, v2f *p1_ring, u
     return hipLaunchKernel(k, dim3(nmax * 128), dim3(512), args, XCH_BYTES + TWI_BYTES + TWO_BYTES, st);
 }
 
+hipError_t setup_small_kernels()
+{
+    // 8192 / 16384-point transforms need 68 / 136 KiB of dynamic LDS
+    const void *ks[4] = {reinterpret_cast<const void *>(&k_small16<13, FWD>), reinterpret_cast<const void *>(&k_small16<13, INV>),
+                         reinterpret_cast<const void *>(&k_small16<14, FWD>), reinterpret_cast<const void *>(&k_small16<14, INV>)};
+    for (int i = 0; i < 4; ++i) {
+        const int n = i < 2 ? 8192 : 16384;
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (n + n / 16) * 8);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t setup_1m_kernels()
 {
     const int big = XCH_BYTES + TWI_BYTES + TWO_BYTES, small = XCH_BYTES + TWI_BYTES;
@@ -696,36 +848,43 @@ hipError_t launch_radix_pass(int dir, int R, const v2f *in, v2f *out, const v2f 
                       : launch_radix_pass_dir<INV>(R, in, out, tw_lo, tw_hi, lg_s, total, st);
 }
 
-// out[t][k1 + R1*(k2 + R2*k3)] = scale * in[t][(k1*R2 + k2)*M + k3]; one thread per (t, k3), reads coalesced
-// over k3, each thread writes Rt = R1*R2 consecutive outputs.
+// out[t][k1 + R1*(k2 + R2*k3)] = scale * in[t][(k1*R2 + k2)*M + k3].  An Rt x M -> M x Rt transpose per
+// transform (Rt = R1*R2), tiled through LDS: a workgroup takes TK = 4096/Rt consecutive k3, reads Rt rows of
+// TK contiguous samples (coalesced) and writes one contiguous 32-KiB block (coalesced); rows are padded by one
+// element so the transposed LDS read is conflict-free.
 __global__ __launch_bounds__(256) void k_permute(const v2f *__restrict__ in, v2f *__restrict__ out, uint32_t lg_r1,
-                                                 uint32_t lg_r2, uint32_t lg_m, uint64_t total /* batch * M */,
-                                                 float scale)
+                                                 uint32_t lg_r2, uint32_t lg_m, float scale)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const uint32_t lg_rt = lg_r1 + lg_r2;
-    const uint64_t t = g >> lg_m;
-    const uint32_t k3 = (uint32_t)(g & ((1u << lg_m) - 1));
-    const v2f *src = in + (t << (lg_m + lg_rt)) + k3;
-    v2f *dst = out + (t << (lg_m + lg_rt)) + ((uint64_t)k3 << lg_rt);
-    const uint32_t Rt = 1u << lg_rt, R1m = (1u << lg_r1) - 1;
-    for (uint32_t q = 0; q < Rt; q += 2) {  // q = k1 + R1*k2 ; Rt >= 2
-        const uint32_t qa = q, qb = q + 1;
-        const v2f a = src[(uint64_t)(((qa & R1m) << lg_r2) + (qa >> lg_r1)) << lg_m] * scale;
-        const v2f b = src[(uint64_t)(((qb & R1m) << lg_r2) + (qb >> lg_r1)) << lg_m] * scale;
-        *reinterpret_cast<v4f *>(dst + q) = v4f{a.x, a.y, b.x, b.y};
+    __shared__ v2f tile[4096 + 128];
+    const uint32_t lg_rt = lg_r1 + lg_r2, Rt = 1u << lg_rt;
+    const uint32_t lg_tk = 12 - lg_rt, TK = 1u << lg_tk;          // k3 per tile
+    const uint32_t tiles_per_x = 1u << (lg_m - lg_tk);
+    const uint64_t t = blockIdx.x / tiles_per_x;
+    const uint32_t k0 = (blockIdx.x % tiles_per_x) << lg_tk;
+    const v2f *src = in + (t << (lg_m + lg_rt));
+    v2f *dst = out + (t << (lg_m + lg_rt)) + ((uint64_t)k0 << lg_rt);
+    const uint32_t R1m = (1u << lg_r1) - 1;
+    for (uint32_t e = threadIdx.x; e < 4096; e += 256) {
+        const uint32_t q = e >> lg_tk, k = e & (TK - 1);           // q = k1 + R1*k2 (output digit order)
+        const uint32_t row = ((q & R1m) << lg_r2) + (q >> lg_r1);  // k1*R2 + k2 (storage order)
+        tile[q * (TK + 1) + k] = src[((uint64_t)row << lg_m) + k0 + k];
+    }
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; o < 4096; o += 256) {
+        const uint32_t k = o >> lg_rt, q = o & (Rt - 1);
+        dst[o] = tile[q * (TK + 1) + k] * scale;
     }
 }
 
 hipError_t launch_permute(const v2f *in, v2f *out, uint32_t lg_r1, uint32_t lg_r2, uint32_t lg_m, uint64_t batch,
                           float scale, hipStream_t st)
 {
-    const uint64_t total = batch << lg_m;
-    if (total == 0) return hipSuccess;
-    const uint64_t blocks = (total + 255) / 256;
+    if (batch == 0) return hipSuccess;
+    const uint32_t lg_rt = lg_r1 + lg_r2;
+    if (lg_rt < 1 || lg_rt > 10 || lg_m + lg_rt < 12) return hipErrorInvalidValue;  // TK = 4096/Rt must divide M
+    const uint64_t blocks = batch << (lg_m + lg_rt - 12);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_permute, dim3((uint32_t)blocks), dim3(256), 0, st, in, out, lg_r1, lg_r2, lg_m, total, scale);
+    hipLaunchKernelGGL(k_permute, dim3((uint32_t)blocks), dim3(256), 0, st, in, out, lg_r1, lg_r2, lg_m, scale);
     return hipGetLastError();
 }
 

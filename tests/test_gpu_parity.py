@@ -39,7 +39,8 @@ def _check(oracle, y, r, n, tol=REL_TOL):
     return worst
 
 
-def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=None, wgs=None, policy=None, mix=None):
+def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=None, wgs=None, policy=None, mix=None,
+         small_reg=None):
     """reference call sequence (examples/basic.rs:73-122): write_buffer -> proc -> read back"""
     src = _upload(fw, dev, queue, x)
     src2 = dev.create_buffer(x.nbytes) if kind in ("Onlyinverse",) else None
@@ -60,6 +61,8 @@ def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=
         plan.set("policy", policy)
     if mix is not None:
         plan.set("mix", mix)
+    if small_reg is not None:
+        plan.set("small_reg", small_reg)
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -104,19 +107,20 @@ def test_reference_known_answers(gpu, known_answers):
         assert which == int(np.log2(n)) % 2    # processor.rs:153-157
 
 
-# ---- K4: numpy float64 fixtures, every power of two 2..1024, both paths ----
-@pytest.mark.parametrize("path", [None, 2])
-def test_fixture_sizes(gpu, oracle, k4, path):
+# ---- K4: numpy float64 fixtures, every power of two 2..1024: register radix-16 kernel (default), LDS radix-2
+# kernel (small_reg=0) and the literal one-launch-per-stage recurrence (path=2) ----
+@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 0), (2, None)])
+def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
     fw, dev, queue = gpu
     for lg in range(1, 11):
         n = 1 << lg
         x = k4[f"x_{n}"]
-        y, which, _ = _run(fw, dev, queue, "Forward", x, n, path=path)
+        y, which, _ = _run(fw, dev, queue, "Forward", x, n, path=path, small_reg=small_reg)
         _check(oracle, y, k4[f"fwd_{n}"], n)
         assert which == lg % 2
-        y, _, _ = _run(fw, dev, queue, "Onlyinverse", x, n, path=path)
+        y, _, _ = _run(fw, dev, queue, "Onlyinverse", x, n, path=path, small_reg=small_reg)
         _check(oracle, y, k4[f"inv_unscaled_{n}"], n)
-        y, _, _ = _run(fw, dev, queue, "Inverse", x, n, path=path)
+        y, _, _ = _run(fw, dev, queue, "Inverse", x, n, path=path, small_reg=small_reg)
         _check(oracle, y, k4[f"inv_unscaled_{n}"] / n, n)
 
 

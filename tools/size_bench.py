@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tools/size_bench.py -- throughput of Forward.proc for every power of two (total 2^28 samples per size,
+C2/C5 shapes with batch 1 as well).  One JSON line per size.  Not part of the product path."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fft_wgpu_amd as fw  # noqa: E402
+
+
+def main():
+    dev, queue = fw.prepare_gpu(0)
+    enc = dev.create_command_encoder()
+    total_lg = 28
+    cases = [(lg, 1 << (total_lg - lg)) for lg in range(1, 25)] + [(20, 1), (24, 1), (10, 1)]
+    buf = dev.create_buffer(8 << total_lg)
+    for lg, batch in cases:
+        n = 1 << lg
+        view = dev.wrap_buffer(buf.device_ptr, n * batch * 8)
+        plan = fw.Forward(dev, queue, view, n)
+        reps = 5 if n * batch >= (1 << 24) else 50
+        times = []
+        for r in range(reps + 1):
+            dev.fill_synthetic(view, n, scale=2.0 ** -20, encoder=enc)
+            a, b = fw.Event(dev), fw.Event(dev)
+            a.record(enc)
+            plan.proc(enc)
+            b.record(enc)
+            if r:
+                times.append(a.elapsed_ms(b))
+        ms = sorted(times)[len(times) // 2]
+        print(json.dumps({"lg_n": lg, "batch": batch, "path": plan.get("path"), "launches": plan.get("launches_per_exec"),
+                          "ms": round(ms, 4), "Gsamples_s": round(n * batch / ms / 1e6, 2),
+                          "roofline_frac": round(16 * n * batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
+        plan.destroy()
+
+
+if __name__ == "__main__":
+    main()
