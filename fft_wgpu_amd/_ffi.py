@@ -49,6 +49,10 @@ _SIGNATURES = {
     "fwa_buf_upload": (_I32, [_P, _U64, _P, _U64, _P]),
     "fwa_buf_download": (_I32, [_P, _P, _U64, _U64, _P]),
     "fwa_buf_copy": (_I32, [_P, _U64, _P, _U64, _U64, _P]),
+    "fwa_host_alloc": (_I32, [_P, _U64, _PP]),
+    "fwa_host_free": (_I32, [_P, _P]),
+    "fwa_buf_download_async": (_I32, [_P, _P, _U64, _U64, _P]),
+    "fwa_stream_wait_stream": (_I32, [_P, _P]),
     "fwa_buf_device_ptr": (_P, [_P]),
     "fwa_buf_size": (_U64, [_P]),
     "fwa_plan_create": (_I32, [_P, _I32, _U32, _P, _P, _PP]),

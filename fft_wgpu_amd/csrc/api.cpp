@@ -387,6 +387,47 @@ int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint
     return FWA_OK;
 }
 
+int32_t fwa_host_alloc(fwa_ctx *ctx, uint64_t bytes, void **out)
+{
+    if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    if (!bytes) return FWA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail_hip(ctx, e, "hipHostMalloc", FWA_ERR_OUT_OF_MEMORY);
+    return FWA_OK;
+}
+
+int32_t fwa_host_free(fwa_ctx *ctx, void *ptr)
+{
+    if (!ptr) return FWA_OK;
+    HIP_TRY(ctx, hipHostFree(ptr));
+    return FWA_OK;
+}
+
+int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes, fwa_stream *stream)
+{
+    if (!src || (!host && bytes)) return fail(src ? src->ctx : nullptr, FWA_ERR_INVALID_ARG, "src/host is NULL");
+    if (src_offset > src->bytes || bytes > src->bytes - src_offset)
+        return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
+    if (!bytes) return FWA_OK;
+    HIP_TRY(src->ctx, hipMemcpyAsync(host, static_cast<const char *>(src->p) + src_offset, bytes,
+                                     hipMemcpyDeviceToHost, raw(stream)));
+    return FWA_OK;
+}
+
+int32_t fwa_stream_wait_stream(fwa_stream *stream, fwa_stream *other)
+{
+    if (!stream || !other) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    hipEvent_t ev;
+    HIP_TRY(stream->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, other->s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream->s, ev, 0);
+    (void)hipEventDestroy(ev);  // destruction is deferred by the runtime until the event has completed
+    if (e != hipSuccess) return fail_hip(stream->ctx, e, "hipEventRecord/hipStreamWaitEvent");
+    return FWA_OK;
+}
+
 void *fwa_buf_device_ptr(const fwa_buf *buf) { return buf ? buf->p : nullptr; }
 uint64_t fwa_buf_size(const fwa_buf *buf) { return buf ? buf->bytes : 0; }
 

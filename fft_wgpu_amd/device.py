@@ -67,6 +67,10 @@ class CommandEncoder:
     def finish(self):
         return self
 
+    def wait_for(self, other):
+        """Device-side dependency: work recorded here after this call runs after everything on `other`."""
+        _ffi.check(_ffi.lib().fwa_stream_wait_stream(self._h, other._h), self.device._h, "fwa_stream_wait_stream")
+
     def synchronize(self):
         _ffi.check(_ffi.lib().fwa_stream_synchronize(self._h), self.device._h, "fwa_stream_synchronize")
 
@@ -168,6 +172,21 @@ class Device:
     def poll(self, encoder=None):
         """device.poll(Maintain::wait()) (examples/basic.rs:106)."""
         (encoder or self._default).synchronize()
+
+    def pinned_array(self, n_elements, dtype=np.complex64):
+        """Page-locked host staging array (the reference's MAP_READ staging buffer, examples/basic.rs:50-55)."""
+        nbytes = int(n_elements) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().fwa_host_alloc(self._h, nbytes, ctypes.byref(p)), self._h, "fwa_host_alloc")
+        arr = np.ctypeslib.as_array((ctypes.c_char * nbytes).from_address(p.value)).view(dtype)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return arr
+
+    def download_async(self, host_array, buffer, encoder, offset=0):
+        st = _ffi.lib().fwa_buf_download_async(host_array.ctypes.data_as(ctypes.c_void_p), buffer._h, offset,
+                                               host_array.nbytes, encoder._h)
+        _ffi.check(st, self._h, "fwa_buf_download_async")
 
     def fill_synthetic(self, buffer, fft_len, seed=0x5EED, first_transform=0, scale=1.0, encoder=None):
         st = _ffi.lib().fwa_fill_synthetic(buffer._h, seed, first_transform, fft_len, scale,

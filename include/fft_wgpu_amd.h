@@ -94,6 +94,16 @@ int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, ui
                          fwa_stream *stream);
 int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint64_t src_offset,
                      uint64_t bytes, fwa_stream *stream);
+/* Pinned (page-locked) host staging memory: with it fwa_buf_upload is truly asynchronous and
+ * fwa_buf_download_async can overlap with transforms on another stream -- the reference's benchmark loop
+ * (examples/basic.rs:72-127: write_buffer -> proc -> copy -> map) pipelined over three streams. */
+int32_t fwa_host_alloc(fwa_ctx *ctx, uint64_t bytes, void **out);
+int32_t fwa_host_free(fwa_ctx *ctx, void *ptr);
+/* Stream-ordered device->host copy that does NOT wait (fwa_buf_download does, like map_async + poll). */
+int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes,
+                               fwa_stream *stream);
+/* Make `stream` wait (on the device) for everything enqueued on `other` so far. */
+int32_t fwa_stream_wait_stream(fwa_stream *stream, fwa_stream *other);
 void *fwa_buf_device_ptr(const fwa_buf *buf);
 uint64_t fwa_buf_size(const fwa_buf *buf);
 
