@@ -62,9 +62,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FWA_BENCH_FORCE_DIST") == "1"  # the env knob exercises the N>1 code path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import fft_wgpu_amd as fw
 
@@ -90,8 +94,8 @@ def main():
     def barrier():
         enc.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
 
     regen()
     for _ in range(args.warmup):
@@ -116,7 +120,7 @@ def main():
     step_ms_events = [a.elapsed_ms(b) for a, b in ev]
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
@@ -179,8 +183,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
