@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,6 +50,7 @@ enum fwa_path : int64_t {
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,
     PATH_FUSED_1M = 5,  // in-place persistent pipeline, one launch per exec
+    PATH_TILED = 7,     // n = N1*N2[*N3], each 64..1024: 2-3 k_tile16 passes (default for 2^15..2^19, 2^21..2^30)
     PATH_SPLIT = 6,     // n = R1*R2*M: strided register-radix passes + fast sub-transforms (M = 2^20 or 4096) + permute
 };
 
@@ -68,6 +70,11 @@ struct fwa_plan {
     v2f *tw_half = nullptr;        // n/2 entries, processor.rs:43-49
     v2f *tw_inner = nullptr;       // 2^20 path: [k1][n'] = W_1024^{n' k1}
     v2f *tw_outer = nullptr;       // 2^20 path: per tile A[32][16], B[32][16]
+    // tiled path (PATH_TILED): log2 of the factors (lf[2] = 0 for two factors), per-factor W_L tables,
+    // four-step tables of pass A (domain n) and pass B (domain N2*N3)
+    uint32_t lf[3] = {0, 0, 0};
+    v2f *tw_l[3] = {nullptr, nullptr, nullptr};
+    v2f *tw_lo_b = nullptr, *tw_hi_b = nullptr;
     // split path (PATH_SPLIT)
     uint32_t r1 = 1, r2 = 1, leaf = 0;  // n = r1 * r2 * leaf
     v2f *tw_lo1 = nullptr, *tw_hi1 = nullptr, *tw_lo2 = nullptr, *tw_hi2 = nullptr;
@@ -439,7 +446,8 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
     if (plan->tw_half) (void)hipFree(plan->tw_half);
     if (plan->tw_inner) (void)hipFree(plan->tw_inner);
     if (plan->tw_outer) (void)hipFree(plan->tw_outer);
-    for (v2f *t : {plan->tw_lo1, plan->tw_hi1, plan->tw_lo2, plan->tw_hi2})
+    for (v2f *t : {plan->tw_lo1, plan->tw_hi1, plan->tw_lo2, plan->tw_hi2, plan->tw_l[0], plan->tw_l[1], plan->tw_l[2],
+                   plan->tw_lo_b, plan->tw_hi_b})
         if (t) (void)hipFree(t);
     if (plan->second_owned && plan->own_second.p) (void)hipFree(plan->own_second.p);
     delete plan;
@@ -488,7 +496,8 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     if (fft_len == 1) p->path = PATH_IDENTITY;
     else if (fft_len <= 16384) p->path = PATH_LDS_SMALL;
     else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;  // PATH_FUSED_1M is opt-in (experimental)
-    else if (fft_len >= (1u << 15) && fft_len <= (1u << 30)) p->path = PATH_SPLIT;
+    else if (fft_len >= (1u << 15) && fft_len <= (1u << 30))
+        p->path = std::getenv("FWA_FORCE_SPLIT") ? PATH_SPLIT : PATH_TILED;  // split kept as a cross-check path
     else p->path = PATH_R2_GLOBAL;
     p->leaf_batch = p->batch;
     if (p->path == PATH_SPLIT) {
@@ -502,7 +511,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
     // materialised when the result must land there (odd log2 n) or the path ping-pongs.
     const bool odd = (p->lg & 1) != 0;
-    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT;
+    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT || p->path == PATH_TILED;
     if (!p->second && need_second && src->bytes) {
         hipError_t e = hipMalloc(&p->own_second.p, src->bytes);
         if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipMalloc(second buffer)"));
@@ -521,15 +530,33 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
         ctx->setup_small_done = true;
     }
+    auto level = [&](uint64_t cur, v2f **lo, v2f **hi) -> int32_t {
+        const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
+        std::vector<v2f> l(nlo), h(nhi);
+        for (uint64_t j = 0; j < nlo; ++j) l[j] = tw_f64(j, cur);
+        for (uint64_t j = 0; j < nhi; ++j) h[j] = tw_f64(1024 * j, cur);
+        int32_t s = upload_table(ctx, l, lo);
+        return s ? s : upload_table(ctx, h, hi);
+    };
+    if (p->path == PATH_TILED) {
+        // factors of 64..1024 each: two for 2^15..2^20, three above
+        const uint32_t nf = p->lg <= 20 ? 2 : 3;
+        for (uint32_t i = 0; i < nf; ++i) p->lf[i] = p->lg / nf + (i >= nf - p->lg % nf ? 1 : 0);
+        for (uint32_t i = 0; i < nf; ++i) {
+            const uint32_t L = 1u << p->lf[i];
+            std::vector<v2f> h(L / 2);
+            for (uint32_t k = 0; k < L / 2; ++k) h[k] = tw_f64(k, L);
+            st = upload_table(ctx, h, &p->tw_l[i]);
+            if (st) return bail(st);
+        }
+        st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
+        if (st) return bail(st);
+        if (nf == 3) {
+            st = level((uint64_t)fft_len >> p->lf[0], &p->tw_lo_b, &p->tw_hi_b);
+            if (st) return bail(st);
+        }
+    }
     if (p->path == PATH_SPLIT) {
-        auto level = [&](uint64_t cur, v2f **lo, v2f **hi) -> int32_t {
-            const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
-            std::vector<v2f> l(nlo), h(nhi);
-            for (uint64_t j = 0; j < nlo; ++j) l[j] = tw_f64(j, cur);
-            for (uint64_t j = 0; j < nhi; ++j) h[j] = tw_f64(1024 * j, cur);
-            int32_t s = upload_table(ctx, l, lo);
-            return s ? s : upload_table(ctx, h, hi);
-        };
         st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
         if (st) return bail(st);
         if (p->r2 > 1) {
@@ -691,6 +718,41 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (s2) return s2;
             break;
         }
+        case PATH_TILED: {
+            // n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3).  Pass A: FFT over n1
+            // (cols, twiddle W_n), [pass B: FFT over n2 per k1 (cols, twiddle W_{N2*N3})], pass C: FFT over the
+            // contiguous axis with the transposed store.  Even log2 n: A goes src -> second and C comes back
+            // into src; odd: A/B in place in src, C into second (processor.rs:153-157).
+            const bool three = plan->lf[2] != 0;
+            const uint64_t N = plan->n, N1 = 1ull << plan->lf[0], N2 = 1ull << plan->lf[1],
+                           N3 = three ? (1ull << plan->lf[2]) : 1;
+            v2f *work = (plan->lg % 2 == 0) ? b : a;
+            fwa::TileArgs ta{};
+            ta.scale = 1.0f;
+            // pass A
+            ta.in = a; ta.out = work; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
+            ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;
+            ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / 16);
+            e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[0], ta, plan->batch, st);
+            if (e != hipSuccess) break;
+            if (three) {  // pass B, in place
+                ta.in = work; ta.out = work; ta.tw = plan->tw_l[1]; ta.tw_lo = plan->tw_lo_b; ta.tw_hi = plan->tw_hi_b;
+                ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1; ta.tile_count = (uint32_t)(N3 / 16);
+                e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[1], ta, plan->batch, st);
+                if (e != hipSuccess) break;
+            }
+            // pass C: rows of length Nlast, 16 adjacent k1 per tile
+            const uint32_t li = three ? 2 : 1;
+            ta.in = work; ta.out = out; ta.tw = plan->tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
+            ta.scale = scale;
+            ta.in_sb = ta.out_sb = N;
+            ta.pitch = N / N1;             // distance between the rows k1 and k1+1
+            ta.in_st = 16 * (N / N1); ta.out_st = 16; ta.tile_count = (uint32_t)(N1 / 16);
+            if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
+            else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
+            e = fwa::launch_tile16(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, plan->batch, st);
+            break;
+        }
         case PATH_SPLIT: {
             // even log2 n: src -> second (pass 1), work in second, permute back into src; odd: work in src,
             // permute into second -- the result lands where processor.rs:153-157 says.
@@ -758,6 +820,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
                 break;
             }
             case PATH_FUSED_1M: *value = 1; break;
+            case PATH_TILED: *value = plan->lf[2] ? 3 : 2; break;
             case PATH_SPLIT: {
                 int64_t leafl = 1;
                 if (plan->leaf == (1u << 20)) {
@@ -818,6 +881,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             plan->path = value;
             return build_pipeline(plan);
         }
+        if (value == PATH_TILED || value == PATH_SPLIT)
+            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "tiled/split are chosen at plan creation (FWA_FORCE_SPLIT=1 selects split)");
         if (value == PATH_R2_GLOBAL && plan->n >= 2) {
             // force the literal reference recurrence (one launch per stage)
             if (!plan->tw_half) {

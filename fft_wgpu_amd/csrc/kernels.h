@@ -12,6 +12,24 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 // completely before any of it is written)
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           hipStream_t st);
+enum { TILE_COLS = 0, TILE_ROWS_T = 1 };
+
+struct TileArgs {
+    const v2f *in;
+    v2f *out;
+    const v2f *tw;      // W_L table (L/2 entries) for the inner stages
+    const v2f *tw_lo;   // four-step twiddle tables (COLS only)
+    const v2f *tw_hi;
+    uint64_t in_sb, in_s1, in_st;     // input base = b*in_sb + d1*in_s1 + tile*in_st
+    uint64_t out_sb, out_s1, out_st;  // output base likewise
+    uint64_t pitch;                   // COLS: element pitch of the FFT axis; ROWS_T: pitch between the 16 rows
+    uint64_t out_stride;              // ROWS_T: element stride between consecutive outputs of a row
+    uint32_t d1_count, tile_count;    // blockIdx.x = (b*d1_count + d1)*tile_count + tile
+    float scale;
+};
+
+// 16 FFTs of length 2^lg_l per workgroup along one axis (kernels.hip: k_tile16); blocks = batch*d1_count*tile_count
+hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
 hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();
 hipError_t launch_p1_1m(int dir, int policy, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,

@@ -260,6 +260,132 @@ hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint
 }
 
 // ---------------------------------------------------------------------------
+// k_tile16: 16 FFTs of length L (64 <= L <= 1024) per workgroup along ONE axis of a multi-dimensional view
+// of the transform -- the building block of the 2- and 3-pass paths for n = 2^15..2^19 and 2^21..2^30
+// (n = N1*N2[*N3]).  Same register radix-16 Stockham stages as k_small16; what differs is addressing:
+//   COLS  (strided axis): element i of FFT c at in + i*pitch + c; 16 adjacent c = one 128-B segment, so
+//         loads and stores are coalesced over c.  Output element o is multiplied by the four-step twiddle
+//         W_T^{(col0 + c)*o} = hi[e>>10]*lo[e&1023] and stored at out + o*pitch + c (in place allowed).
+//   ROWS_T (last axis): FFT c is a contiguous row at in + c*row_pitch; loads are coalesced along the row,
+//         the exchange re-maps threads, and output element o of row c goes to out + o*out_stride + c
+//         (16 adjacent rows = one 128-B segment): the transposed store that restores natural order.
+// ---------------------------------------------------------------------------
+template <int LGL, int DIR, int MODE>
+__global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
+{
+    constexpr int L = 1 << LGL;
+    constexpr int TPX = L / 16;
+    constexpr int NS16 = LGL / 4;
+    constexpr int RL = 1 << (LGL % 4);
+    constexpr int PADN = L + L / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f *lds_all = reinterpret_cast<v2f *>(smem);
+    auto pad = [](uint32_t p) { return p + (p >> 4); };
+
+    const uint32_t tile = blockIdx.x % a.tile_count;
+    const uint32_t rest = blockIdx.x / a.tile_count;
+    const uint32_t d1 = rest % a.d1_count;
+    const uint64_t b = rest / a.d1_count;
+    const v2f *in = a.in + b * a.in_sb + d1 * a.in_s1 + tile * a.in_st;
+    v2f *out = a.out + b * a.out_sb + d1 * a.out_s1 + tile * a.out_st;
+
+    // mapping B (FFT index fastest): coalesces every access whose 16 FFTs are adjacent in memory
+    const uint32_t cB = threadIdx.x & 15, tB = threadIdx.x >> 4;
+    // mapping A (position fastest): coalesces along a contiguous row
+    const uint32_t cA = threadIdx.x / TPX, tA = threadIdx.x % TPX;
+    const uint32_t c0 = (MODE == TILE_COLS) ? cB : cA, t0 = (MODE == TILE_COLS) ? tB : tA;
+
+    // stage 0: global -> LDS (L >= 64, so there is always a later stage)
+    {
+        v2f *lds = lds_all + c0 * PADN;
+        stage_bfly<16, L, DIR>(
+            [&](uint32_t i) { return (MODE == TILE_COLS) ? in[(uint64_t)i * a.pitch + c0] : in[(uint64_t)c0 * a.pitch + i]; },
+            [&](uint32_t o, v2f v) { lds[pad(o)] = v; }, a.tw, t0, 1u);
+    }
+    v2f *lds = lds_all + cB * PADN;
+    const uint32_t t = tB;
+    auto emit = [&](uint32_t o, v2f v) {
+        if constexpr (MODE == TILE_COLS) {
+            const uint32_t e = ((uint32_t)(tile * 16) + cB) * o;  // (column index within the twiddle domain) * k
+            if (o) v = cmul_tw<DIR>(v, cmul(a.tw_hi[e >> 10], a.tw_lo[e & 1023]));
+            out[(uint64_t)o * a.pitch + cB] = v * a.scale;
+        } else {
+            out[(uint64_t)o * a.out_stride + cB] = v * a.scale;
+        }
+    };
+    uint32_t J = 16;
+    static_for<1, NS16>([&](auto s_) {
+        constexpr int st = decltype(s_)::value;
+        constexpr bool last = (st == NS16 - 1) && RL == 1;
+        __syncthreads();
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * (L / 16))]; });
+        if constexpr (!last) __syncthreads();
+        fft_reg<16, DIR>(x);
+        const uint32_t j = t & (J - 1), sJ = t - j;
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            v2f v = x[brev<16>(q)];
+            if constexpr (q != 0 && !last) v = cmul_tw<DIR>(v, tw_lookup<L>(a.tw, sJ * q));
+            const uint32_t o = sJ * 16 + j + q * J;
+            if constexpr (last) emit(o, v);
+            else lds[pad(o)] = v;
+        });
+        J *= 16;
+    });
+    if constexpr (RL > 1) {
+        __syncthreads();
+        static_for<0, 16 / RL>([&](auto b_) {
+            constexpr int bb = decltype(b_)::value;
+            stage_bfly<RL, L, DIR>([&](uint32_t i) { return lds[pad(i)]; }, emit, a.tw, t + bb * TPX, J);
+        });
+    }
+}
+
+template <int DIR, int MODE>
+static hipError_t launch_tile16_mode(uint32_t lg_l, const TileArgs &a, uint64_t blocks, hipStream_t st)
+{
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const uint32_t L = 1u << lg_l;
+    const size_t lds = (size_t)16 * (L + L / 16) * sizeof(v2f);
+    const dim3 g((uint32_t)blocks), blk(L);
+    const void *k = nullptr;
+    switch (lg_l) {
+        case 6: k = reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE>); break;
+        case 7: k = reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE>); break;
+        case 8: k = reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE>); break;
+        case 9: k = reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE>); break;
+        case 10: k = reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE>); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (lds > 65536) {
+        static const void *done[32];  // attribute set once per kernel (plan creation warms every kernel a plan uses)
+        static int n_done = 0;
+        bool seen = false;
+        for (int i = 0; i < n_done; ++i) seen |= (done[i] == k);
+        if (!seen) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            if (n_done < 32) done[n_done++] = k;
+        }
+    }
+    TileArgs copy = a;
+    void *args[] = {&copy};
+    return hipLaunchKernel(k, g, blk, args, lds, st);
+}
+
+hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st)
+{
+    const uint64_t blocks = batch * a.d1_count * a.tile_count;
+    if (dir == FWD)
+        return mode == TILE_COLS ? launch_tile16_mode<FWD, TILE_COLS>(lg_l, a, blocks, st)
+                                 : launch_tile16_mode<FWD, TILE_ROWS_T>(lg_l, a, blocks, st);
+    return mode == TILE_COLS ? launch_tile16_mode<INV, TILE_COLS>(lg_l, a, blocks, st)
+                             : launch_tile16_mode<INV, TILE_ROWS_T>(lg_l, a, blocks, st);
+}
+
+// ---------------------------------------------------------------------------
 // n = 2^20 = 1024 x 1024, two passes.
 //
 // Index algebra (n = 1024*n1 + n2, k = K1 + 1024*K2):

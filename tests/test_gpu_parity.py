@@ -139,7 +139,7 @@ def test_literal_recurrence_matches_restatement_bitwise_shape(gpu, oracle):
 # ---- size sweep incl. ragged batches, 64-bit-free small cases ----
 @pytest.mark.parametrize("lg,batch", [(0, 5), (1, 7), (2, 1), (3, 1000), (4, 1), (5, 33), (6, 129), (9, 2500),
                                       (10, 1), (11, 5), (12, 3), (13, 2), (14, 3), (15, 3), (16, 2), (17, 5), (18, 1),
-                                      (19, 3), (21, 1), (22, 3), (23, 1)])
+                                      (19, 3), (21, 1), (22, 3), (23, 1), (25, 1)])
 def test_size_sweep(gpu, oracle, lg, batch):
     fw, dev, queue = gpu
     n = 1 << lg
@@ -230,7 +230,7 @@ def test_config_c5_n16m_batch1(gpu, oracle):
     n = 1 << 24
     x = oracle.gen_input(n, 1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n)
-    assert which == 0 and plan.get("path") == 6  # split: radix-16 pass + 16 x 2^20 pipeline + permute
+    assert which == 0 and plan.get("path") == 7  # tiled: 256 x 256 x 256, three k_tile16 passes
     mx, l2 = _check(oracle, y, oracle.dft_f64(x, n, -1), n)
     print("C5 max_rel %.3g rel_l2 %.3g" % (mx, l2))
 
@@ -361,3 +361,20 @@ def test_cpp_mirror_replays_reference_example(gpu, tmp_path):
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "max error 0" in r.stdout
+
+
+def test_split_path_cross_check(gpu, oracle):
+    """FWA_FORCE_SPLIT=1 selects the older split decomposition (strided radix passes + sub-transforms +
+    permute) for 2^15..2^30; both decompositions must agree with the fp64 DFT."""
+    import os
+    fw, dev, queue = gpu
+    os.environ["FWA_FORCE_SPLIT"] = "1"
+    try:
+        for lg, batch in ((15, 3), (18, 2), (21, 1), (24, 1)):
+            n = 1 << lg
+            x = oracle.gen_input(n, batch, first_transform=lg)
+            y, which, plan = _run(fw, dev, queue, "Forward", x, n)
+            assert plan.get("path") == 6 and which == lg % 2
+            _check(oracle, y, oracle.dft_f64(x, n, -1), n)
+    finally:
+        del os.environ["FWA_FORCE_SPLIT"]
