@@ -84,6 +84,7 @@ struct fwa_plan {
     int64_t group = 8;             // transforms per launch pair
     int64_t n_streams = 2;         // internal streams the groups alternate over
     uint64_t ring_slots = 0;
+    uint64_t slot_bytes = 0;
     // fused 2^20 pipeline
     uint32_t *fused_ctl = nullptr;
     int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
@@ -176,9 +177,11 @@ int32_t build_pipeline(fwa_plan *p)
     const uint64_t n_groups = pbatch ? (pbatch + p->group - 1) / p->group : 0;
     if (p->n_streams < 1) p->n_streams = 1;
     if ((uint64_t)p->n_streams > n_groups && n_groups) p->n_streams = (int64_t)n_groups;
-    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams * (p->mix ? 2 : 1);
+    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams * ((p->mix && p->path != PATH_TILED) ? 2 : 1);
     if (p->ring_slots == 0) return FWA_OK;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->ring), p->ring_slots * (sizeof(v2f) << 20)));
+    // one slot = one (sub-)transform of the pipeline: 2^20 samples on the two-pass paths, n on the tiled path
+    p->slot_bytes = (p->path == PATH_TILED) ? (uint64_t)p->n * sizeof(v2f) : (sizeof(v2f) << 20);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->ring), p->ring_slots * p->slot_bytes));
     if (p->n_streams > 1) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         for (int64_t i = 0; i < p->n_streams; ++i) {
@@ -511,7 +514,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
     // materialised when the result must land there (odd log2 n) or the path ping-pongs.
     const bool odd = (p->lg & 1) != 0;
-    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT || p->path == PATH_TILED;
+    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT;
     if (!p->second && need_second && src->bytes) {
         hipError_t e = hipMalloc(&p->own_second.p, src->bytes);
         if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipMalloc(second buffer)"));
@@ -555,6 +558,12 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
             st = level((uint64_t)fft_len >> p->lf[0], &p->tw_lo_b, &p->tw_hi_b);
             if (st) return bail(st);
         }
+        // intermediate of a group of transforms lives in a cache-sized ring slab (64 MiB per chain)
+        const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
+        p->group = (int64_t)((64ull << 20) / per);
+        if (p->group < 1) p->group = 1;
+        st = build_pipeline(p);
+        if (st) return bail(st);
     }
     if (p->path == PATH_SPLIT) {
         st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
@@ -719,38 +728,57 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             break;
         }
         case PATH_TILED: {
-            // n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3).  Pass A: FFT over n1
-            // (cols, twiddle W_n), [pass B: FFT over n2 per k1 (cols, twiddle W_{N2*N3})], pass C: FFT over the
-            // contiguous axis with the transposed store.  Even log2 n: A goes src -> second and C comes back
-            // into src; odd: A/B in place in src, C into second (processor.rs:153-157).
+            // n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3).  Per group of transforms:
+            // pass A: FFT over n1 (cols, twiddle W_n), user buffer -> ring slab; [pass B: FFT over n2 per k1 (cols,
+            // twiddle W_{N2*N3}), in place in the slab]; pass C: FFT over the contiguous axis with the transposed
+            // store, slab -> result buffer (src for even log2 n -- in place at group granularity -- else second).
             const bool three = plan->lf[2] != 0;
             const uint64_t N = plan->n, N1 = 1ull << plan->lf[0], N2 = 1ull << plan->lf[1],
                            N3 = three ? (1ull << plan->lf[2]) : 1;
-            v2f *work = (plan->lg % 2 == 0) ? b : a;
-            fwa::TileArgs ta{};
-            ta.scale = 1.0f;
-            // pass A
-            ta.in = a; ta.out = work; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
-            ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;
-            ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / 16);
-            e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[0], ta, plan->batch, st);
-            if (e != hipSuccess) break;
-            if (three) {  // pass B, in place
-                ta.in = work; ta.out = work; ta.tw = plan->tw_l[1]; ta.tw_lo = plan->tw_lo_b; ta.tw_hi = plan->tw_hi_b;
-                ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1; ta.tile_count = (uint32_t)(N3 / 16);
-                e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[1], ta, plan->batch, st);
-                if (e != hipSuccess) break;
+            const uint64_t G = (uint64_t)plan->group, n_groups = (plan->batch + G - 1) / G;
+            const size_t ns = plan->istreams.size();
+            if (ns) {
+                HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
+                for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
             }
-            // pass C: rows of length Nlast, 16 adjacent k1 per tile
-            const uint32_t li = three ? 2 : 1;
-            ta.in = work; ta.out = out; ta.tw = plan->tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
-            ta.scale = scale;
-            ta.in_sb = ta.out_sb = N;
-            ta.pitch = N / N1;             // distance between the rows k1 and k1+1
-            ta.in_st = 16 * (N / N1); ta.out_st = 16; ta.tile_count = (uint32_t)(N1 / 16);
-            if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
-            else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
-            e = fwa::launch_tile16(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, plan->batch, st);
+            for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
+                const uint64_t cnt = (plan->batch - g * G < G) ? plan->batch - g * G : G;
+                const size_t c = ns ? (size_t)(g % ns) : 0;
+                hipStream_t s = ns ? plan->istreams[c] : st;
+                v2f *slab = plan->ring + (uint64_t)c * G * N;
+                fwa::TileArgs ta{};
+                ta.scale = 1.0f;
+                // pass A
+                ta.in = a + g * G * N; ta.out = slab; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
+                ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;
+                ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / 16);
+                e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
+                if (e != hipSuccess) break;
+                if (three) {  // pass B, in place in the slab
+                    ta.in = slab; ta.out = slab; ta.tw = plan->tw_l[1]; ta.tw_lo = plan->tw_lo_b; ta.tw_hi = plan->tw_hi_b;
+                    ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1;
+                    ta.tile_count = (uint32_t)(N3 / 16);
+                    e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[1], ta, cnt, s);
+                    if (e != hipSuccess) break;
+                }
+                // pass C: rows of the last axis, 16 adjacent k1 per tile
+                const uint32_t li = three ? 2 : 1;
+                ta.in = slab; ta.out = out + g * G * N; ta.tw = plan->tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
+                ta.scale = scale;
+                ta.in_sb = ta.out_sb = N;
+                ta.pitch = N / N1;  // distance between the rows k1 and k1+1
+                ta.in_st = 16 * (N / N1); ta.out_st = 16; ta.tile_count = (uint32_t)(N1 / 16);
+                if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
+                else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
+                e = fwa::launch_tile16(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, cnt, s);
+            }
+            if (e != hipSuccess) break;
+            if (ns) {
+                for (size_t i = 0; i < ns; ++i) {
+                    HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
+                    HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
+                }
+            }
             break;
         }
         case PATH_SPLIT: {
@@ -808,7 +836,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         }
     }
     else if (k == "scratch_bytes")
-        *value = (int64_t)(plan->ring_slots * (sizeof(v2f) << 20)) +
+        *value = (int64_t)(plan->ring_slots * plan->slot_bytes) +
                  (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
                  (plan->fused_ctl ? (int64_t)fwa::fused_ctl_bytes(plan->batch) : 0);
     else if (k == "launches_per_exec") {
@@ -820,7 +848,9 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
                 break;
             }
             case PATH_FUSED_1M: *value = 1; break;
-            case PATH_TILED: *value = plan->lf[2] ? 3 : 2; break;
+            case PATH_TILED:
+                *value = (plan->lf[2] ? 3 : 2) * (int64_t)((plan->batch + plan->group - 1) / plan->group);
+                break;
             case PATH_SPLIT: {
                 int64_t leafl = 1;
                 if (plan->leaf == (1u << 20)) {
@@ -845,7 +875,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (plan->frozen) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "plan tunables are locked after the first exec");
     const std::string k(key);
     if (k == "group" || k == "streams") {
-        if (plan->path != PATH_TWOPASS_1M && !(plan->path == PATH_SPLIT && plan->leaf == (1u << 20)))
+        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED && !(plan->path == PATH_SPLIT && plan->leaf == (1u << 20)))
             return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 pipeline");
         if (value < 1 || value > 4096) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
         if (k == "group") plan->group = value; else plan->n_streams = value;
