@@ -551,6 +551,8 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
             for (uint32_t k = 0; k < L / 2; ++k) h[k] = tw_f64(k, L);
             st = upload_table(ctx, h, &p->tw_l[i]);
             if (st) return bail(st);
+            hipError_t pe = fwa::prepare_tile16(p->lf[i]);
+            if (pe != hipSuccess) return bail(fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)"));
         }
         st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
         if (st) return bail(st);

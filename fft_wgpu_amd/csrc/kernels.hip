@@ -343,36 +343,44 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
 }
 
 template <int DIR, int MODE>
+static const void *tile16_kernel(uint32_t lg_l)
+{
+    switch (lg_l) {
+        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE>);
+        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE>);
+        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE>);
+        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE>);
+        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE>);
+        default: return nullptr;
+    }
+}
+static size_t tile16_lds(uint32_t lg_l) { return (size_t)16 * ((1u << lg_l) + (1u << lg_l) / 16) * sizeof(v2f); }
+
+// called at plan creation: raises the dynamic-LDS limit of the kernels a plan will launch (L >= 512)
+hipError_t prepare_tile16(uint32_t lg_l)
+{
+    const size_t lds = tile16_lds(lg_l);
+    if (lds <= 65536) return hipSuccess;
+    const void *ks[4] = {tile16_kernel<FWD, TILE_COLS>(lg_l), tile16_kernel<FWD, TILE_ROWS_T>(lg_l),
+                         tile16_kernel<INV, TILE_COLS>(lg_l), tile16_kernel<INV, TILE_ROWS_T>(lg_l)};
+    for (const void *k : ks) {
+        if (!k) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int DIR, int MODE>
 static hipError_t launch_tile16_mode(uint32_t lg_l, const TileArgs &a, uint64_t blocks, hipStream_t st)
 {
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const uint32_t L = 1u << lg_l;
-    const size_t lds = (size_t)16 * (L + L / 16) * sizeof(v2f);
-    const dim3 g((uint32_t)blocks), blk(L);
-    const void *k = nullptr;
-    switch (lg_l) {
-        case 6: k = reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE>); break;
-        case 7: k = reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE>); break;
-        case 8: k = reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE>); break;
-        case 9: k = reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE>); break;
-        case 10: k = reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE>); break;
-        default: return hipErrorInvalidValue;
-    }
-    if (lds > 65536) {
-        static const void *done[32];  // attribute set once per kernel (plan creation warms every kernel a plan uses)
-        static int n_done = 0;
-        bool seen = false;
-        for (int i = 0; i < n_done; ++i) seen |= (done[i] == k);
-        if (!seen) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            if (n_done < 32) done[n_done++] = k;
-        }
-    }
+    const void *k = tile16_kernel<DIR, MODE>(lg_l);
+    if (!k) return hipErrorInvalidValue;
     TileArgs copy = a;
     void *args[] = {&copy};
-    return hipLaunchKernel(k, g, blk, args, lds, st);
+    return hipLaunchKernel(k, dim3((uint32_t)blocks), dim3(1u << lg_l), args, tile16_lds(lg_l), st);
 }
 
 hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st)

@@ -36,11 +36,11 @@ class _Plan:
         for b in (self.buffer_a, self.buffer_b):
             if b is not None and b._h is not None and b._h.value == res.value:
                 return b
-        # plan-owned second buffer (Forward/Inverse with odd log2 n): borrowed view, never freed here
-        key = res.value
-        if key not in self._results:
-            self._results[key] = Buffer(self.device, ctypes.c_void_p(key), borrowed=True)
-        return self._results[key]
+        # plan-owned second buffer (Forward/Inverse with odd log2 n): a borrowed view that keeps the plan
+        # alive (the Rust API ties it to the plan's lifetime: `proc(&self) -> &wgpu::Buffer`)
+        view = Buffer(self.device, ctypes.c_void_p(res.value), borrowed=True)
+        view._plan = self
+        return view
 
     def get(self, key):
         v = ctypes.c_int64()

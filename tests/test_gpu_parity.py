@@ -67,7 +67,7 @@ def _run(fw, dev, queue, kind, x, n, path=None, group=None, streams=None, depth=
     out = plan.proc(enc)
     queue.submit(enc.finish())
     y = out.map_read(stream=enc)
-    which = 0 if out is src else 1
+    which = 0 if (out is src or out.device_ptr == src.device_ptr) else 1
     assert plan.get("device_error") == 0
     return y, which, plan
 
@@ -378,3 +378,17 @@ def test_split_path_cross_check(gpu, oracle):
             _check(oracle, y, oracle.dft_f64(x, n, -1), n)
     finally:
         del os.environ["FWA_FORCE_SPLIT"]
+
+
+def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):
+    """Forward/Inverse with odd log2 n return a view of the plan's own second buffer (processor.rs:13,153-157);
+    the view must keep the plan alive, as the Rust borrow does."""
+    import gc
+    fw, dev, queue = gpu
+    x = oracle.gen_input(512, 4)
+    src = _upload(fw, dev, queue, x)
+    enc = dev.create_command_encoder()
+    out = fw.Forward(dev, queue, src, 512).proc(enc)   # the plan object is a temporary
+    gc.collect()
+    y = out.map_read(stream=enc)
+    _check(oracle, y, oracle.dft_f64(x, 512, -1), 512)
