@@ -542,8 +542,10 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return s ? s : upload_table(ctx, h, hi);
     };
     if (p->path == PATH_TILED) {
-        // factors of 64..1024 each: two for 2^15..2^20, three above
-        const uint32_t nf = p->lg <= 20 ? 2 : 3;
+        // factors of 64..1024 each.  Tiles of 512/1024-point FFTs leave one or two workgroups per CU and run
+        // slower per pass than three passes of <= 256-point tiles (measured: 2^18 as 512x512 3.0 ms vs
+        // 64x64x64 ~2.5 ms per 2^28 samples), so two factors only while both stay <= 512
+        const uint32_t nf = p->lg <= 17 ? 2 : 3;
         for (uint32_t i = 0; i < nf; ++i) p->lf[i] = p->lg / nf + (i >= nf - p->lg % nf ? 1 : 0);
         for (uint32_t i = 0; i < nf; ++i) {
             const uint32_t L = 1u << p->lf[i];

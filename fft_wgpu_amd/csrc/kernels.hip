@@ -304,10 +304,25 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     }
     v2f *lds = lds_all + cB * PADN;
     const uint32_t t = tB;
-    auto emit = [&](uint32_t o, v2f v) {
+    // Four-step twiddle (COLS).  Every output of this thread has index o = t + m*TPX, m = 0..15, so
+    // W_T^{col*o} = [W^{col*t} * (W^{col*TPX})^(m&3)] * W^{col*TPX*4*(m>>2)}: four table look-ups
+    // (hi[e>>10]*lo[e&1023] each) and short products instead of one look-up pair per output.
+    v2f pa[4], pb[4];
+    if constexpr (MODE == TILE_COLS) {
+        const uint32_t col = tile * 16 + cB;
+        auto look = [&](uint32_t e) { return cmul(a.tw_hi[e >> 10], a.tw_lo[e & 1023]); };
+        const v2f wt = look(col * t), p1 = look(col * TPX);
+        pa[0] = v2f{1.f, 0.f}; pa[1] = look(col * (4 * TPX)); pa[2] = look(col * (8 * TPX)); pa[3] = cmul(pa[2], pa[1]);
+        pb[0] = wt; pb[1] = cmul(wt, p1);
+        const v2f p2 = cmul(p1, p1);
+        pb[2] = cmul(wt, p2); pb[3] = cmul(pb[2], p1);
+    }
+    // output m of this thread: index o = t + m*TPX (m is a compile-time constant at every call site)
+    auto emit = [&](auto m_, v2f v) {
+        constexpr uint32_t m = decltype(m_)::value;
+        const uint32_t o = t + m * TPX;
         if constexpr (MODE == TILE_COLS) {
-            const uint32_t e = ((uint32_t)(tile * 16) + cB) * o;  // (column index within the twiddle domain) * k
-            if (o) v = cmul_tw<DIR>(v, cmul(a.tw_hi[e >> 10], a.tw_lo[e & 1023]));
+            v = cmul_tw<DIR>(v, cmul(pa[m >> 2], pb[m & 3]));
             out[(uint64_t)o * a.pitch + cB] = v * a.scale;
         } else {
             out[(uint64_t)o * a.out_stride + cB] = v * a.scale;
@@ -326,18 +341,31 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
         static_for<0, 16>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             v2f v = x[brev<16>(q)];
-            if constexpr (q != 0 && !last) v = cmul_tw<DIR>(v, tw_lookup<L>(a.tw, sJ * q));
-            const uint32_t o = sJ * 16 + j + q * J;
-            if constexpr (last) emit(o, v);
-            else lds[pad(o)] = v;
+            if constexpr (last) {
+                emit(q_, v);  // last stage: J = TPX, s = 0, o = t + q*TPX
+            } else {
+                if constexpr (q != 0) v = cmul_tw<DIR>(v, tw_lookup<L>(a.tw, sJ * q));
+                lds[pad(sJ * 16 + j + q * J)] = v;
+            }
         });
         J *= 16;
     });
     if constexpr (RL > 1) {
+        // last stage of radix RL < 16: butterflies idx = t + b*TPX, inputs idx + m*L/RL, output q at
+        // idx + q*L/RL = t + (b + q*16/RL)*TPX; s = 0, so no stage twiddle
         __syncthreads();
         static_for<0, 16 / RL>([&](auto b_) {
             constexpr int bb = decltype(b_)::value;
-            stage_bfly<RL, L, DIR>([&](uint32_t i) { return lds[pad(i)]; }, emit, a.tw, t + bb * TPX, J);
+            v2f x[RL];
+            static_for<0, RL>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+                x[m] = lds[pad(t + bb * TPX + m * (L / RL))];
+            });
+            fft_reg<RL, DIR>(x);
+            static_for<0, RL>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                emit(std::integral_constant<int, bb + q * (16 / RL)>{}, x[brev<RL>(q)]);
+            });
         });
     }
 }
