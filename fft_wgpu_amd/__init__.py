@@ -9,3 +9,13 @@ from .device import (Buffer, CommandEncoder, Device, Event, Queue, device_count,
 from .processor import Forward, Inverse, Normalize, Onlyinverse  # noqa: F401
 
 COMPLEX_BYTES = 8  # src/lib.rs:10-15: {real: f32, imag: f32}
+
+
+def describe_path(fft_len):
+    """(path id, [per-pass FFT lengths]) a plan of this length will use -- pure host logic, no GPU needed."""
+    import ctypes
+    from . import _ffi
+    path = ctypes.c_int32()
+    lf = (ctypes.c_uint32 * 3)()
+    _ffi.check(_ffi.lib().fwa_describe_path(fft_len, ctypes.byref(path), ctypes.byref(lf)), None, "fwa_describe_path")
+    return path.value, [1 << v for v in lf if v]

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "fwa_plan_create": (_I32, [_P, _I32, _U32, _P, _P, _PP]),
     "fwa_plan_exec": (_I32, [_P, _P, _PP]),
     "fwa_plan_destroy": (_I32, [_P]),
+    "fwa_describe_path": (_I32, [_U32, ctypes.POINTER(_I32), ctypes.POINTER(_U32 * 3)]),
     "fwa_plan_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "fwa_plan_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
     "fwa_event_create": (_I32, [_P, _PP]),

@@ -129,6 +129,25 @@ uint32_t ilog2(uint32_t n)
     return l;
 }
 
+// Path and per-pass FFT lengths (log2) for a transform length; shared by fwa_plan_create and fwa_describe_path.
+int64_t choose_path(uint32_t n, uint32_t lf[3])
+{
+    lf[0] = lf[1] = lf[2] = 0;
+    const uint32_t lg = ilog2(n);
+    if (n == 1) return PATH_IDENTITY;
+    if (n <= 16384) { lf[0] = lg; return PATH_LDS_SMALL; }
+    if (n == (1u << 20)) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
+    if (n <= (1u << 30)) {
+        // factors of 64..1024 each.  Tiles of 512/1024-point FFTs leave one or two workgroups per CU and run
+        // slower per pass than three passes of <= 256-point tiles (measured: 2^18 as 512x512 3.0 ms vs
+        // 64x64x64 2.3 ms per 2^28 samples), so two factors only while both stay <= 512
+        const uint32_t nf = lg <= 17 ? 2 : 3;
+        for (uint32_t i = 0; i < nf; ++i) lf[i] = lg / nf + (i >= nf - lg % nf ? 1 : 0);
+        return PATH_TILED;
+    }
+    return PATH_R2_GLOBAL;
+}
+
 // reference twiddle rule, processor.rs:43-49: f64 math, rounded to f32.
 v2f tw_f64(uint64_t k, uint64_t n)
 {
@@ -496,12 +515,8 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return FWA_OK;
     }
 
-    if (fft_len == 1) p->path = PATH_IDENTITY;
-    else if (fft_len <= 16384) p->path = PATH_LDS_SMALL;
-    else if (fft_len == (1u << 20)) p->path = PATH_TWOPASS_1M;  // PATH_FUSED_1M is opt-in (experimental)
-    else if (fft_len >= (1u << 15) && fft_len <= (1u << 30))
-        p->path = std::getenv("FWA_FORCE_SPLIT") ? PATH_SPLIT : PATH_TILED;  // split kept as a cross-check path
-    else p->path = PATH_R2_GLOBAL;
+    p->path = choose_path(fft_len, p->lf);  // PATH_FUSED_1M is opt-in (experimental)
+    if (p->path == PATH_TILED && std::getenv("FWA_FORCE_SPLIT")) p->path = PATH_SPLIT;  // cross-check path
     p->leaf_batch = p->batch;
     if (p->path == PATH_SPLIT) {
         p->leaf = (fft_len > (1u << 20)) ? (1u << 20) : 4096u;
@@ -542,11 +557,7 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return s ? s : upload_table(ctx, h, hi);
     };
     if (p->path == PATH_TILED) {
-        // factors of 64..1024 each.  Tiles of 512/1024-point FFTs leave one or two workgroups per CU and run
-        // slower per pass than three passes of <= 256-point tiles (measured: 2^18 as 512x512 3.0 ms vs
-        // 64x64x64 ~2.5 ms per 2^28 samples), so two factors only while both stay <= 512
-        const uint32_t nf = p->lg <= 17 ? 2 : 3;
-        for (uint32_t i = 0; i < nf; ++i) p->lf[i] = p->lg / nf + (i >= nf - p->lg % nf ? 1 : 0);
+        const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i) {
             const uint32_t L = 1u << p->lf[i];
             std::vector<v2f> h(L / 2);
@@ -708,7 +719,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
             break;
         case PATH_LDS_SMALL:
-            if (plan->small_reg && plan->n >= 16)
+            if (plan->small_reg && plan->n < 16)
+                e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
+            else if (plan->small_reg)
                 e = fwa::launch_small16(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
             else
                 e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
@@ -812,6 +825,15 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "plan path not implemented");
     }
     if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
+    return FWA_OK;
+}
+
+int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors[3])
+{
+    if (!path || !log2_factors) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    if (!is_pow2(fft_len)) return fail(nullptr, FWA_ERR_INVALID_ARG, "fft_len must be a power of two >= 1");
+    if (fft_len > (1u << 30)) return fail(nullptr, FWA_ERR_UNSUPPORTED, "fft_len above 2^30 is not supported");
+    *path = (int32_t)choose_path(fft_len, log2_factors);
     return FWA_OK;
 }
 

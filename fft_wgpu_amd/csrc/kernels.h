@@ -31,6 +31,8 @@ struct TileArgs {
 // 16 FFTs of length 2^lg_l per workgroup along one axis (kernels.hip: k_tile16); blocks = batch*d1_count*tile_count
 hipError_t prepare_tile16(uint32_t lg_l);
 hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
+// n = 2, 4, 8 (in place allowed)
+hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
 hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();
 hipError_t launch_p1_1m(int dir, int policy, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,

@@ -121,6 +121,65 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 }
 
 // ---------------------------------------------------------------------------
+// n = 2, 4, 8: each thread owns 16 consecutive samples (16/n whole transforms), one radix-n butterfly
+// network per transform in registers, 16-byte loads and stores.
+// ---------------------------------------------------------------------------
+template <int N, int DIR>
+__global__ __launch_bounds__(256) void k_tiny(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
+                                              float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
+    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n_samples; base += stride) {
+        v2f x[16];
+        if (base + 16 <= n_samples) {
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                const v4f v = *reinterpret_cast<const v4f *>(src + base + 2 * i);
+                x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w};
+            });
+        } else {
+            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = (base + i < n_samples) ? src[base + i] : v2f{0.f, 0.f}; });
+        }
+        v2f y[16];
+        static_for<0, 16 / N>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            v2f t[N];
+            static_for<0, N>([&](auto i_) { constexpr int i = decltype(i_)::value; t[i] = x[g * N + i]; });
+            fft_reg<N, DIR>(t);
+            static_for<0, N>([&](auto k_) { constexpr int k = decltype(k_)::value; y[g * N + k] = t[brev<N>(k)] * scale; });
+        });
+        if (base + 16 <= n_samples) {
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                *reinterpret_cast<v4f *>(dst + base + 2 * i) = v4f{y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y};
+            });
+        } else {
+            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; if (base + i < n_samples) dst[base + i] = y[i]; });
+        }
+    }
+}
+
+hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st)
+{
+    const uint64_t n_samples = batch * n;
+    if (n_samples == 0) return hipSuccess;
+    uint64_t blocks = (n_samples / 16 + 255) / 256 + 1;
+    if (blocks > 16384) blocks = 16384;
+    const dim3 g((uint32_t)blocks), b(256);
+#define FWA_TINY(NN)                                                                                        \
+    if (dir == FWD) hipLaunchKernelGGL((k_tiny<NN, FWD>), g, b, 0, st, src, dst, n_samples, scale);         \
+    else hipLaunchKernelGGL((k_tiny<NN, INV>), g, b, 0, st, src, dst, n_samples, scale)
+    switch (n) {
+        case 2: FWA_TINY(2); break;
+        case 4: FWA_TINY(4); break;
+        case 8: FWA_TINY(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FWA_TINY
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // small transforms, 16 <= n <= 4096: register radix-16 Stockham.  Each thread owns 16 points; a transform
 // uses n/16 threads; stages are radix 16, 16, ... and a last stage of radix n / 16^k (2, 4 or 8 -- the
 // thread then does 16/R butterflies).  Stage recurrence = the reference's (fft.wgsl:27-62) with the pair

@@ -131,6 +131,11 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
 int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result);
 int32_t fwa_plan_destroy(fwa_plan *plan);
 
+/* Pure host logic, no device needed: which path and factorisation a plan of length fft_len uses.
+ * *path as in fwa_plan_get_i64("path"); log2_factors[0..2] = log2 of the per-pass FFT lengths
+ * (0 = unused), e.g. 2^20 -> {10,10,0}, 2^24 -> {8,8,8}, 512 -> {9,0,0}. */
+int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors[3]);
+
 /* Introspection / tuning (no reference analogue).  Keys for fwa_plan_get_i64:
  *   "batch", "fft_len", "path" (0 lds-small, 1 two-launch 2^20, 2 radix-2 global, 3 normalize, 4 identity,
  *   5 fused in-place 2^20), "launches_per_exec", "scratch_bytes", "group", "streams" (two-launch path),
