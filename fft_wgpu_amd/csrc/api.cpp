@@ -89,7 +89,7 @@ struct fwa_plan {
     uint32_t *fused_ctl = nullptr;
     int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
     int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
-    int64_t small_reg = 1;         // n in [16, 4096]: 1 = register radix-16 kernel, 0 = LDS radix-2 kernel
+    int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
     int64_t mix = 1;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
     int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels.hip)
     int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
@@ -722,7 +722,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (plan->small_reg && plan->n < 16)
                 e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
             else if (plan->small_reg)
-                e = fwa::launch_small16(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
+                e = fwa::launch_small16(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
             else
                 e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
             break;
@@ -814,7 +814,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 if (s2) return s2;
             } else {
                 e = plan->small_reg
-                        ? fwa::launch_small16(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st)
+                        ? fwa::launch_small16(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, false, st)
                         : fwa::launch_lds_small(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st);
                 if (e != hipSuccess) break;
             }
@@ -910,7 +910,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "dbg") { plan->dbg = value; return FWA_OK; }
     if (k == "small_reg") {
         if (!value && plan->n > 4096) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
-        plan->small_reg = value ? 1 : 0;
+        plan->small_reg = value == 2 ? 2 : (value ? 1 : 0);  // 2: wavefront-shuffle exchange at n = 32/64/128
         return FWA_OK;
     }
     if (k == "mix") {

@@ -10,8 +10,9 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
                             hipStream_t st);
 // 16 <= n <= 16384: register radix-16 Stockham (one launch); src == dst allowed (a transform is read
 // completely before any of it is written)
+// wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                          hipStream_t st);
+                          bool wave_shuffle, hipStream_t st);
 enum { TILE_COLS = 0, TILE_ROWS_T = 1 };
 
 struct TileArgs {

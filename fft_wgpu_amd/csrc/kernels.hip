@@ -214,7 +214,33 @@ __device__ __forceinline__ void stage_bfly(Get get, Put put, const v2f *__restri
     });
 }
 
-template <int LGN, int DIR>
+// In-wave exchange for n = 32, 64, 128 (one radix-16 stage + one radix-R stage, R = n/16 lanes per
+// transform): the element in (lane m, register b*R + r) moves to (lane r, register b*R + m) -- an R x R
+// transpose per register group, done as log2(R) butterfly steps of `__shfl_xor` + select.  No LDS memory, no
+// barrier.  Measured 3-10 % SLOWER than the padded-LDS exchange at these sizes (ds_bpermute issue cost), so the
+// plan uses it only when asked (small_reg = 2); DPP quad-permute moves miscompiled under hipcc 7.2 (one of two
+// back-to-back moves of a float2 dropped) and are not used.
+template <int R>
+__device__ __forceinline__ void wave_transpose(v2f (&x)[16], uint32_t lane_in_group)
+{
+    static_for<0, ilog2c(R)>([&](auto s_) {
+        constexpr int sft = decltype(s_)::value;
+        const bool hi = (lane_in_group >> sft) & 1;
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q0 = decltype(q_)::value;
+            if constexpr (((q0 % R) >> sft & 1) == 0) {
+                constexpr int q1 = q0 | (1 << sft);
+                const v2f send = hi ? x[q0] : x[q1];
+                v2f recv;
+                recv.x = __shfl_xor(send.x, 1 << sft);
+                recv.y = __shfl_xor(send.y, 1 << sft);
+                if (hi) x[q0] = recv; else x[q1] = recv;
+            }
+        });
+    });
+}
+
+template <int LGN, int DIR, bool SHFL = false>
 __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small16(const v2f *__restrict__ src,
                                                                                   v2f *__restrict__ dst,
                                                                                   const v2f *__restrict__ tw,
@@ -236,6 +262,30 @@ __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small1
     v2f *g_out = dst + xf * N;
     auto pad = [](uint32_t p) { return p + (p >> 4); };
 
+    if constexpr (SHFL && NS16 == 1 && RL > 1) {
+        // n = 32, 64, 128: radix-16 from global, wavefront shuffle exchange, radix-RL to global
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = live ? g_in[t + m * TPX] : v2f{0.f, 0.f}; });
+        fft_reg<16, DIR>(x);
+        v2f y[16];
+        static_for<0, 16>([&](auto q_) {  // stage-0 output q of thread t sits at t*16 + q; twiddle W_n^{t*q}
+            constexpr int q = decltype(q_)::value;
+            y[q] = x[brev<16>(q)];
+            if constexpr (q != 0) y[q] = cmul_tw<DIR>(y[q], tw_lookup<N>(tw, t * q));
+        });
+        wave_transpose<RL>(y, t);  // y[b*RL + m] = input m of butterfly idx = t + b*RL
+        static_for<0, 16 / RL>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            v2f z[RL];
+            static_for<0, RL>([&](auto m_) { constexpr int m = decltype(m_)::value; z[m] = y[b * RL + m]; });
+            fft_reg<RL, DIR>(z);
+            static_for<0, RL>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if (live) g_out[t + b * RL + q * 16] = z[brev<RL>(q)] * scale;  // idx + q*J, J = 16
+            });
+        });
+        return;
+    }
     // stage 0: global -> (LDS | global)
     {
         constexpr bool only = (NS16 == 1 && RL == 1);
@@ -282,20 +332,29 @@ __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small1
 
 template <int DIR>
 static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t batch, float scale,
-                                     hipStream_t st)
+                                     bool shfl, hipStream_t st)
 {
     const uint32_t n = 1u << lg_n;
     const uint32_t wg = lg_n <= 12 ? 256 : n / 16;
     const uint32_t xpw = wg / (n / 16);
     const uint64_t blocks = (batch + xpw - 1) / xpw;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (lg_n == 4) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
+    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
     const dim3 g((uint32_t)blocks), b(wg);
     switch (lg_n) {
         case 4: hipLaunchKernelGGL((k_small16<4, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 5: hipLaunchKernelGGL((k_small16<5, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 6: hipLaunchKernelGGL((k_small16<6, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 7: hipLaunchKernelGGL((k_small16<7, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 5:
+            if (shfl) hipLaunchKernelGGL((k_small16<5, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<5, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
+        case 6:
+            if (shfl) hipLaunchKernelGGL((k_small16<6, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<6, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
+        case 7:
+            if (shfl) hipLaunchKernelGGL((k_small16<7, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<7, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
         case 8: hipLaunchKernelGGL((k_small16<8, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 9: hipLaunchKernelGGL((k_small16<9, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 10: hipLaunchKernelGGL((k_small16<10, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
@@ -309,13 +368,13 @@ static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, ui
 }
 
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                          hipStream_t st)
+                          bool wave_shuffle, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
     uint32_t lg_n = 0;
     while ((1u << lg_n) < n) ++lg_n;
-    return dir == FWD ? launch_small16_dir<FWD>(src, dst, tw, lg_n, batch, scale, st)
-                      : launch_small16_dir<INV>(src, dst, tw, lg_n, batch, scale, st);
+    return dir == FWD ? launch_small16_dir<FWD>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st)
+                      : launch_small16_dir<INV>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st);
 }
 
 // ---------------------------------------------------------------------------

@@ -108,8 +108,9 @@ def test_reference_known_answers(gpu, known_answers):
 
 
 # ---- K4: numpy float64 fixtures, every power of two 2..1024: register radix-16 kernel (default), LDS radix-2
-# kernel (small_reg=0) and the literal one-launch-per-stage recurrence (path=2) ----
-@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 0), (2, None)])
+# kernel (small_reg=0), the wavefront-shuffle exchange at n = 32/64/128 (small_reg=2) and the literal
+# one-launch-per-stage recurrence (path=2) ----
+@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 2), (None, 0), (2, None)])
 def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
     fw, dev, queue = gpu
     for lg in range(1, 11):
