@@ -765,6 +765,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 v2f *slab = plan->ring + (uint64_t)c * G * N;
                 fwa::TileArgs ta{};
                 ta.scale = 1.0f;
+                ta.flags = (uint32_t)plan->dbg;
                 // pass A
                 ta.in = a + g * G * N; ta.out = slab; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;

@@ -427,7 +427,7 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     // (hi[e>>10]*lo[e&1023] each) and short products instead of one look-up pair per output.
     v2f pa[4], pb[4];
     if constexpr (MODE == TILE_COLS) {
-        const uint32_t col = tile * 16 + cB;
+        const uint32_t col = (a.flags & 1) ? 0u : tile * 16 + cB;  // flags&1: timing-only, all twiddles = 1
         auto look = [&](uint32_t e) { return cmul(a.tw_hi[e >> 10], a.tw_lo[e & 1023]); };
         const v2f wt = look(col * t), p1 = look(col * TPX);
         pa[0] = v2f{1.f, 0.f}; pa[1] = look(col * (4 * TPX)); pa[2] = look(col * (8 * TPX)); pa[3] = cmul(pa[2], pa[1]);
