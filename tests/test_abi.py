@@ -97,3 +97,13 @@ def test_path_selection_host_logic():
     assert e.value.status == 1
     with pytest.raises(fw.FwaError):
         fw.describe_path(0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary must be consumable from C (and hence from Rust bindgen / cgo / JNI): C99, no warnings."""
+    import subprocess
+    src = tmp_path / "c_user.c"
+    src.write_text('#include "fft_wgpu_amd.h"\n'
+                   'int probe(void) { fwa_ctx *c = 0; int32_t n = 0; (void)c; return fwa_device_count(&n) + fwa_abi_version(); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "c_user.o")])

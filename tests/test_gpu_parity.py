@@ -393,3 +393,31 @@ def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):
     gc.collect()
     y = out.map_read(stream=enc)
     _check(oracle, y, oracle.dft_f64(x, 512, -1), 512)
+
+
+def test_large_single_transform_properties(gpu):
+    """n = 2^27 (1 GiB per transform, three 512-point passes, 64-bit offsets inside ONE transform): no CPU FFT of
+    that size; size-independent properties instead -- an impulse at p transforms to exp(-2*pi*i*p*k/n) (every
+    output checked), and forward followed by the scaled inverse restores the input bit pattern to <= 1e-5."""
+    fw, dev, queue = gpu
+    lg = 27
+    n = 1 << lg
+    if dev.info()["hbm_bytes"] < 16 * 2 ** 30:
+        pytest.skip("needs ~6 GiB of device memory")
+    p = 3 * 5 * 7 * 11 * 13 + 2 ** 20
+    x = np.zeros(n, dtype=np.complex64)
+    x[p] = 1
+    src = _upload(fw, dev, queue, x)
+    plan = fw.Forward(dev, queue, src, n)
+    assert plan.get("path") == 7
+    enc = dev.create_command_encoder()
+    out = plan.proc(enc)
+    y = out.map_read(stream=enc)
+    assert (out.device_ptr == src.device_ptr) == (lg % 2 == 0)
+    k = np.arange(n, dtype=np.int64)
+    ph = ((p * k) % n).astype(np.float64) * (-2.0 * np.pi / n)
+    err = max(np.abs(y.real - np.cos(ph)).max(), np.abs(y.imag - np.sin(ph)).max())
+    assert err <= REL_TOL, err
+    inv = fw.Inverse(dev, queue, out, n)
+    z = inv.proc(enc).map_read(stream=enc)
+    assert np.abs(z - x).max() <= REL_TOL
