@@ -421,3 +421,23 @@ def test_large_single_transform_properties(gpu):
     inv = fw.Inverse(dev, queue, out, n)
     z = inv.proc(enc).map_read(stream=enc)
     assert np.abs(z - x).max() <= REL_TOL
+
+
+def test_seeded_fuzz_over_sizes_kinds_and_batches(gpu, oracle):
+    """60 seeded random (n, batch, plan kind) combinations, ragged batches included, against the fp64 DFT."""
+    fw, dev, queue = gpu
+    rng = np.random.default_rng(20251004)
+    for case in range(60):
+        lg = int(rng.integers(0, 19))
+        n = 1 << lg
+        batch = int(rng.integers(1, max(2, min(3000, (1 << 21) >> lg) + 1)))
+        kind = ("Forward", "Inverse", "Onlyinverse")[int(rng.integers(0, 3))]
+        x = oracle.gen_input(n, batch, first_transform=case)
+        y, which, _ = _run(fw, dev, queue, kind, x, n)
+        assert which == lg % 2, (case, lg, batch, kind)
+        r = oracle.dft_f64(x, n, -1 if kind == "Forward" else +1)
+        if kind == "Inverse":
+            r = r / n
+        for t in (0, batch // 2, batch - 1):
+            mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
+            assert mx <= REL_TOL and l2 <= REL_TOL, (case, lg, batch, kind, t, mx, l2)
