@@ -784,7 +784,12 @@ __global__ __launch_bounds__(512, 4) void k_mix_1m(const v2f *__restrict__ p1_sr
     v2f *twi = reinterpret_cast<v2f *>(smem + XCH_BYTES);
     v2f *two = reinterpret_cast<v2f *>(smem + XCH_BYTES + TWI_BYTES);
     const uint32_t tid = threadIdx.x;
-    const uint32_t role = blockIdx.x & 1, idx = blockIdx.x >> 1;
+    // role assignment: blocks are dealt round-robin over the 8 XCDs, so `blockIdx & 1` would put every pass-1
+    // tile on four XCDs and every pass-2 tile on the other four; bit 3 instead gives each XCD both roles
+    // (dbg & 128 selects the old split, for A/B timing).
+    uint32_t role, idx;
+    if (dbg & 128) { role = blockIdx.x & 1; idx = blockIdx.x >> 1; }
+    else { role = (blockIdx.x >> 3) & 1; idx = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7); }
     const bool skel = (dbg & 32) != 0;  // timing-only: memory skeleton
     const uint32_t tile = idx & 63;
     const uint64_t t = idx >> 6;
