@@ -11,6 +11,30 @@
 
 namespace fwa {
 
+// Buffer (SRD) addressing: one 32-bit per-lane byte offset + a scalar offset per access, so the 32 loads
+// and 32 stores of a tile need no per-access VALU address math (cdna_hip_programming.md T8/T20).  The
+// descriptor covers exactly one 8-MiB transform; out-of-range lanes would read 0 / drop the store.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr uint32_t TRANSFORM_BYTES = 8u << 20;
+// cache-policy bits of the aux operand (gfx940+): sc0 = 1, nt = 2, sc1 = 16
+constexpr int AUX_DEFAULT = 0, AUX_NT = 2, AUX_SC1 = 16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const v2f *transform_base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(transform_base), 0, TRANSFORM_BYTES, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ v2f buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
+}
+
+
 // ---------------------------------------------------------------------------
 // radix-2 Stockham stage in global memory (generic fallback, any power of two)
 // ---------------------------------------------------------------------------
@@ -388,7 +412,7 @@ hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint
 //         the exchange re-maps threads, and output element o of row c goes to out + o*out_stride + c
 //         (16 adjacent rows = one 128-B segment): the transposed store that restores natural order.
 // ---------------------------------------------------------------------------
-template <int LGL, int DIR, int MODE>
+template <int LGL, int DIR, int MODE, bool BUF>
 __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
 {
     constexpr int L = 1 << LGL;
@@ -413,12 +437,32 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     const uint32_t cA = threadIdx.x / TPX, tA = threadIdx.x % TPX;
     const uint32_t c0 = (MODE == TILE_COLS) ? cB : cA, t0 = (MODE == TILE_COLS) ? tB : tA;
 
-    // stage 0: global -> LDS (L >= 64, so there is always a later stage)
+    // Addressing.  BUF (every byte offset of the tile < 2^32, checked by the launcher): buffer loads/stores
+    // with one 32-bit per-lane offset and a scalar offset per access -- no 64-bit multiply per element
+    // (cdna_hip_programming.md T8); otherwise plain 64-bit pointers (only the largest transforms).
+    const uint32_t pitch32 = (uint32_t)a.pitch, ostride32 = (uint32_t)a.out_stride;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in), 0, 0xFFFFFFFFu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0xFFFFFFFFu, 0x00020000);
+    const uint32_t vin = (MODE == TILE_COLS) ? (t0 * pitch32 + c0) * 8 : (c0 * pitch32 + t0) * 8;
+    const uint32_t sin_step = (MODE == TILE_COLS) ? (uint32_t)(L / 16) * pitch32 * 8 : (uint32_t)(L / 16) * 8;
+
+    // stage 0: global -> LDS (L >= 64, so there is always a later stage); inputs i = t0 + m*L/16
     {
         v2f *lds = lds_all + c0 * PADN;
-        stage_bfly<16, L, DIR>(
-            [&](uint32_t i) { return (MODE == TILE_COLS) ? in[(uint64_t)i * a.pitch + c0] : in[(uint64_t)c0 * a.pitch + i]; },
-            [&](uint32_t o, v2f v) { lds[pad(o)] = v; }, a.tw, t0, 1u);
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr (BUF) x[m] = buf_load<AUX_DEFAULT>(rin, vin, m * sin_step);
+            else x[m] = (MODE == TILE_COLS) ? in[(uint64_t)(t0 + m * (L / 16)) * a.pitch + c0]
+                                            : in[(uint64_t)c0 * a.pitch + t0 + m * (L / 16)];
+        });
+        fft_reg<16, DIR>(x);
+        static_for<0, 16>([&](auto q_) {  // J = 1: s = t0, output position t0*16 + q, twiddle W_L^{t0*q}
+            constexpr int q = decltype(q_)::value;
+            v2f v = x[brev<16>(q)];
+            if constexpr (q != 0) v = cmul_tw<DIR>(v, tw_lookup<L>(a.tw, t0 * q));
+            lds[t0 * 17 + q] = v;  // pad(t0*16 + q) = t0*16 + q + t0
+        });
     }
     v2f *lds = lds_all + cB * PADN;
     const uint32_t t = tB;
@@ -440,10 +484,13 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
         constexpr uint32_t m = decltype(m_)::value;
         const uint32_t o = t + m * TPX;
         if constexpr (MODE == TILE_COLS) {
-            v = cmul_tw<DIR>(v, cmul(pa[m >> 2], pb[m & 3]));
-            out[(uint64_t)o * a.pitch + cB] = v * a.scale;
+            v = cmul_tw<DIR>(v, cmul(pa[m >> 2], pb[m & 3])) * a.scale;
+            if constexpr (BUF) buf_store<AUX_DEFAULT>(v, rout, (t * pitch32 + cB) * 8, m * (uint32_t)TPX * pitch32 * 8);
+            else out[(uint64_t)o * a.pitch + cB] = v;
         } else {
-            out[(uint64_t)o * a.out_stride + cB] = v * a.scale;
+            v = v * a.scale;
+            if constexpr (BUF) buf_store<AUX_DEFAULT>(v, rout, (t * ostride32 + cB) * 8, m * (uint32_t)TPX * ostride32 * 8);
+            else out[(uint64_t)o * a.out_stride + cB] = v;
         }
     };
     uint32_t J = 16;
@@ -488,17 +535,22 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     }
 }
 
-template <int DIR, int MODE>
-static const void *tile16_kernel(uint32_t lg_l)
+template <int DIR, int MODE, bool BUF>
+static const void *tile16_kernel_b(uint32_t lg_l)
 {
     switch (lg_l) {
-        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE>);
-        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE>);
-        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE>);
-        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE>);
-        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE>);
+        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE, BUF>);
+        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE, BUF>);
+        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE, BUF>);
+        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE, BUF>);
+        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE, BUF>);
         default: return nullptr;
     }
+}
+template <int DIR, int MODE>
+static const void *tile16_kernel(uint32_t lg_l, bool buf = true)
+{
+    return buf ? tile16_kernel_b<DIR, MODE, true>(lg_l) : tile16_kernel_b<DIR, MODE, false>(lg_l);
 }
 static size_t tile16_lds(uint32_t lg_l) { return (size_t)16 * ((1u << lg_l) + (1u << lg_l) / 16) * sizeof(v2f); }
 
@@ -507,8 +559,10 @@ hipError_t prepare_tile16(uint32_t lg_l)
 {
     const size_t lds = tile16_lds(lg_l);
     if (lds <= 65536) return hipSuccess;
-    const void *ks[4] = {tile16_kernel<FWD, TILE_COLS>(lg_l), tile16_kernel<FWD, TILE_ROWS_T>(lg_l),
-                         tile16_kernel<INV, TILE_COLS>(lg_l), tile16_kernel<INV, TILE_ROWS_T>(lg_l)};
+    const void *ks[8] = {tile16_kernel<FWD, TILE_COLS>(lg_l, true),  tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true),
+                         tile16_kernel<INV, TILE_COLS>(lg_l, true),  tile16_kernel<INV, TILE_ROWS_T>(lg_l, true),
+                         tile16_kernel<FWD, TILE_COLS>(lg_l, false), tile16_kernel<FWD, TILE_ROWS_T>(lg_l, false),
+                         tile16_kernel<INV, TILE_COLS>(lg_l, false), tile16_kernel<INV, TILE_ROWS_T>(lg_l, false)};
     for (const void *k : ks) {
         if (!k) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -522,7 +576,12 @@ static hipError_t launch_tile16_mode(uint32_t lg_l, const TileArgs &a, uint64_t 
 {
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const void *k = tile16_kernel<DIR, MODE>(lg_l);
+    // 32-bit byte offsets inside one tile?  COLS: L rows of `pitch`; ROWS_T: 16 rows of `pitch` in, L outputs of out_stride
+    const uint64_t L = 1ull << lg_l;
+    const uint64_t span = (MODE == TILE_COLS) ? L * a.pitch * 8 + 128
+                                              : ((16 * a.pitch + L) * 8 > (L * a.out_stride + 16) * 8 ? (16 * a.pitch + L) * 8
+                                                                                                    : (L * a.out_stride + 16) * 8);
+    const void *k = tile16_kernel<DIR, MODE>(lg_l, span < (1ull << 32));
     if (!k) return hipErrorInvalidValue;
     TileArgs copy = a;
     void *args[] = {&copy};
@@ -555,29 +614,6 @@ hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, ui
 constexpr int XCH_BYTES = 65536;
 constexpr int TWI_BYTES = 8192;
 constexpr int TWO_BYTES = 8192;
-
-// Buffer (SRD) addressing: one 32-bit per-lane byte offset + a scalar offset per access, so the 32 loads
-// and 32 stores of a tile need no per-access VALU address math (cdna_hip_programming.md T8/T20).  The
-// descriptor covers exactly one 8-MiB transform; out-of-range lanes would read 0 / drop the store.
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-constexpr uint32_t TRANSFORM_BYTES = 8u << 20;
-// cache-policy bits of the aux operand (gfx940+): sc0 = 1, nt = 2, sc1 = 16
-constexpr int AUX_DEFAULT = 0, AUX_NT = 2, AUX_SC1 = 16;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const v2f *transform_base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(transform_base), 0, TRANSFORM_BYTES, 0x00020000);
-}
-template <int AUX>
-__device__ __forceinline__ v2f buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
-{
-    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
-}
-template <int AUX>
-__device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
-}
 
 template <int DIR>
 __device__ __forceinline__ void stage1_fft_twiddle(v2f (&x)[32], const v2f *twi, uint32_t q)
