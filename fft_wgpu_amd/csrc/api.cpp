@@ -91,7 +91,7 @@ struct fwa_plan {
     int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
     int64_t mix = 1;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
-    int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels.hip)
+    int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels_1m.hip)
     int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;

@@ -1,0 +1,57 @@
+// device_common.h -- device helpers shared by the kernel translation units (gfx950 only).
+#pragma once
+#include "kernels.h"
+
+namespace fwa {
+
+// Buffer (SRD) addressing: one 32-bit per-lane byte offset + a scalar offset per access, so the 32 loads
+// and 32 stores of a tile need no per-access VALU address math (cdna_hip_programming.md T8/T20).  The
+// descriptor covers exactly one 8-MiB transform; out-of-range lanes would read 0 / drop the store.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr uint32_t TRANSFORM_BYTES = 8u << 20;
+// cache-policy bits of the aux operand (gfx940+): sc0 = 1, nt = 2, sc1 = 16
+constexpr int AUX_DEFAULT = 0, AUX_NT = 2, AUX_SC1 = 16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const v2f *transform_base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(transform_base), 0, TRANSFORM_BYTES, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ v2f buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
+}
+
+
+template <int N>
+__device__ __forceinline__ v2f tw_lookup(const v2f *__restrict__ tw, uint32_t e)  // W_N^e, 0 <= e < N
+{
+    const v2f w = tw[e & (N / 2 - 1)];
+    return (e & (N / 2)) ? -w : w;
+}
+
+template <int R, int N, int DIR, class Get, class Put>
+__device__ __forceinline__ void stage_bfly(Get get, Put put, const v2f *__restrict__ tw, uint32_t idx, uint32_t J)
+{
+    // one radix-R butterfly of the Stockham stage with sub-block size J
+    v2f x[R];
+    static_for<0, R>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = get(idx + m * (N / R)); });
+    fft_reg<R, DIR>(x);
+    const uint32_t j = idx & (J - 1);
+    const uint32_t sJ = idx - j;  // s*J
+    static_for<0, R>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        v2f v = x[brev<R>(q)];
+        if constexpr (q != 0) {
+            if (J * R < N) v = cmul_tw<DIR>(v, tw_lookup<N>(tw, sJ * q));  // last stage: s = 0, no twiddle
+        }
+        put(sJ * R + j + q * J, v);
+    });
+}
+
+}  // namespace fwa

@@ -1,4 +1,4 @@
-// kernels.h -- launch wrappers implemented in kernels.hip (internal to the library).
+// kernels.h -- launch wrappers implemented in kernels_{small,tiled,1m}.hip (internal to the library).
 #pragma once
 #include "cplx.h"
 
@@ -30,7 +30,7 @@ struct TileArgs {
     uint32_t flags;                   // timing-only ablations (0 in the product path)
 };
 
-// 16 FFTs of length 2^lg_l per workgroup along one axis (kernels.hip: k_tile16); blocks = batch*d1_count*tile_count
+// 16 FFTs of length 2^lg_l per workgroup along one axis (kernels_tiled.hip: k_tile16); blocks = batch*d1_count*tile_count
 hipError_t prepare_tile16(uint32_t lg_l);
 hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
 // n = 2, 4, 8 (in place allowed)
@@ -43,7 +43,7 @@ hipError_t launch_p2_1m(int dir, int policy, const v2f *ring, v2f *dst, const v2
                         uint64_t t_first, uint32_t n_transforms, float scale, hipStream_t st);
 size_t fused_ctl_bytes(uint64_t batch);
 // In-place persistent pipeline; `ctl` = fused_ctl_bytes(batch) bytes of device memory (zeroed here per call).
-// Needs >= 64 resident workgroups to be deadlock-free (see kernels.hip); batch*128 tickets must fit in u32.
+// Needs >= 64 resident workgroups to be deadlock-free (see kernels_1m.hip); batch*128 tickets must fit in u32.
 hipError_t launch_fused_1m(int dir, int policy, v2f *data, const v2f *tw_inner, const v2f *tw_outer, uint32_t *ctl,
                            uint32_t batch, uint32_t depth, uint32_t n_workgroups, float scale, uint32_t dbg,
                            hipStream_t st);

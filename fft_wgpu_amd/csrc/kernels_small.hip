@@ -1,0 +1,437 @@
+// kernels_small.hip -- (1/3: one-launch kernels for n <= 16384, radix-2 fallback, elementwise)
+// kernels_*.hip -- hand-written gfx950 kernels of the batched 1-D c2c fp32 FFT.
+//
+// Reference mapping (all under /root/reference/src):
+//   k_r2_stage      <- kernel/fft.wgsl:27-62, ifft.wgsl:25-75 (one butterfly per thread, one launch per stage)
+//   k_lds_small     <- kernel/fft4.wgsl:13-112 (one dispatch, all stages) staged in LDS as kernel/fft2.wgsl:9-10 intended
+//   k_p1_1m/k_p2_1m <- kernel/fft4.wgsl at fft_len = 2^20 (config C2/C3), re-designed: two LDS-tiled
+//                      passes of 32x32 register FFTs, intermediate in a small cache-resident ring
+//   k_normalize     <- kernel/normalize.wgsl:9-12
+// Wavefront = 64, 16-waves-per-CU residency (2 x 512-thread workgroups) for the 2^20 passes.
+#include "device_common.h"
+
+namespace fwa {
+
+// ---------------------------------------------------------------------------
+// radix-2 Stockham stage in global memory (generic fallback, any power of two)
+// ---------------------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(256) void k_r2_stage(const v2f *__restrict__ src, v2f *__restrict__ dst,
+                                                  const v2f *__restrict__ tw, uint32_t n, uint32_t lg_half,
+                                                  uint32_t stage, uint64_t total_bf, float scale)
+{
+    const uint32_t half = n >> 1;
+    const uint32_t J = 1u << stage;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_bf; idx += stride) {
+        const uint64_t t = idx >> lg_half;
+        const uint32_t i = (uint32_t)(idx & (half - 1));
+        const uint32_t j = i & (J - 1);
+        const uint32_t sJ = i - j;  // block_idx * J  (fft.wgsl:37 twiddles[s*J])
+        const uint64_t base = t * (uint64_t)n;
+        const v2f a = src[base + i];
+        const v2f b = src[base + i + half];
+        const v2f w = tw[sJ];
+        const uint64_t o1 = base + ((uint64_t)sJ << 1) + j;
+        dst[o1] = (a + b) * scale;
+        dst[o1 + J] = cmul_tw<DIR>(a - b, w) * scale;
+    }
+}
+
+hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint32_t stage,
+                           uint64_t batch, float scale, hipStream_t st)
+{
+    const uint64_t total = batch * (uint64_t)(n >> 1);
+    if (total == 0) return hipSuccess;
+    uint32_t lg_half = 0;
+    while ((1u << lg_half) < (n >> 1)) ++lg_half;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > (1u << 20)) blocks = (1u << 20);
+    if (dir == FWD)
+        hipLaunchKernelGGL(k_r2_stage<FWD>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, tw, n, lg_half, stage,
+                           total, scale);
+    else
+        hipLaunchKernelGGL(k_r2_stage<INV>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, tw, n, lg_half, stage,
+                           total, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// small transforms (n <= 4096): whole transforms staged in LDS, all stages in one launch
+// ---------------------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(256) void k_lds_small(const v2f *__restrict__ src, v2f *__restrict__ dst,
+                                                   const v2f *__restrict__ tw, uint32_t lg_n, uint32_t lg_p,
+                                                   uint64_t batch, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t n = 1u << lg_n;
+    const uint32_t P = 1u << lg_p;  // points per workgroup (>= n)
+    v2f *bufA = reinterpret_cast<v2f *>(smem);
+    v2f *bufB = bufA + P;
+    const uint32_t tpb = P >> lg_n;  // transforms per block
+    const uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t remaining = batch - t0;  // > 0 by grid construction
+    const uint32_t valid = (uint32_t)((remaining < tpb ? remaining : tpb) << lg_n);  // valid points in this block
+    const v2f *g_in = src + t0 * n;
+    v2f *g_out = dst + t0 * n;
+
+    for (uint32_t p = threadIdx.x; p < P; p += 256) bufA[p] = (p < valid) ? g_in[p] : v2f{0.f, 0.f};
+    __syncthreads();
+
+    const uint32_t half = n >> 1;
+    v2f *a = bufA, *b = bufB;
+    for (uint32_t stage = 0; stage < lg_n; ++stage) {
+        const uint32_t J = 1u << stage;
+        for (uint32_t idx = threadIdx.x; idx < (P >> 1); idx += 256) {
+            const uint32_t tl = idx >> (lg_n - 1);
+            const uint32_t i = idx & (half - 1);
+            const uint32_t j = i & (J - 1);
+            const uint32_t sJ = i - j;
+            const uint32_t base = tl << lg_n;
+            const v2f x = a[base + i], y = a[base + i + half];
+            const v2f w = tw[sJ];
+            const uint32_t o1 = base + (sJ << 1) + j;
+            b[o1] = x + y;
+            b[o1 + J] = cmul_tw<DIR>(x - y, w);
+        }
+        __syncthreads();
+        v2f *t = a; a = b; b = t;
+    }
+    for (uint32_t p = threadIdx.x; p < valid; p += 256) g_out[p] = a[p] * scale;
+}
+
+hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                            hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    uint32_t lg_n = 0;
+    while ((1u << lg_n) < n) ++lg_n;
+    const uint32_t lg_p = lg_n < 11 ? 11 : lg_n;  // 2048 points per block, 4096 for n = 4096
+    const uint32_t tpb = 1u << (lg_p - lg_n);
+    const uint64_t blocks = (batch + tpb - 1) / tpb;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * sizeof(v2f) << lg_p;
+    if (dir == FWD)
+        hipLaunchKernelGGL(k_lds_small<FWD>, dim3((uint32_t)blocks), dim3(256), lds, st, src, dst, tw, lg_n, lg_p, batch,
+                           scale);
+    else
+        hipLaunchKernelGGL(k_lds_small<INV>, dim3((uint32_t)blocks), dim3(256), lds, st, src, dst, tw, lg_n, lg_p, batch,
+                           scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// n = 2, 4, 8: each thread owns 16 consecutive samples (16/n whole transforms), one radix-n butterfly
+// network per transform in registers, 16-byte loads and stores.
+// ---------------------------------------------------------------------------
+template <int N, int DIR>
+__global__ __launch_bounds__(256) void k_tiny(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
+                                              float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
+    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n_samples; base += stride) {
+        v2f x[16];
+        if (base + 16 <= n_samples) {
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                const v4f v = *reinterpret_cast<const v4f *>(src + base + 2 * i);
+                x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w};
+            });
+        } else {
+            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = (base + i < n_samples) ? src[base + i] : v2f{0.f, 0.f}; });
+        }
+        v2f y[16];
+        static_for<0, 16 / N>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            v2f t[N];
+            static_for<0, N>([&](auto i_) { constexpr int i = decltype(i_)::value; t[i] = x[g * N + i]; });
+            fft_reg<N, DIR>(t);
+            static_for<0, N>([&](auto k_) { constexpr int k = decltype(k_)::value; y[g * N + k] = t[brev<N>(k)] * scale; });
+        });
+        if (base + 16 <= n_samples) {
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                *reinterpret_cast<v4f *>(dst + base + 2 * i) = v4f{y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y};
+            });
+        } else {
+            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; if (base + i < n_samples) dst[base + i] = y[i]; });
+        }
+    }
+}
+
+hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st)
+{
+    const uint64_t n_samples = batch * n;
+    if (n_samples == 0) return hipSuccess;
+    uint64_t blocks = (n_samples / 16 + 255) / 256 + 1;
+    if (blocks > 16384) blocks = 16384;
+    const dim3 g((uint32_t)blocks), b(256);
+#define FWA_TINY(NN)                                                                                        \
+    if (dir == FWD) hipLaunchKernelGGL((k_tiny<NN, FWD>), g, b, 0, st, src, dst, n_samples, scale);         \
+    else hipLaunchKernelGGL((k_tiny<NN, INV>), g, b, 0, st, src, dst, n_samples, scale)
+    switch (n) {
+        case 2: FWA_TINY(2); break;
+        case 4: FWA_TINY(4); break;
+        case 8: FWA_TINY(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FWA_TINY
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// small transforms, 16 <= n <= 4096: register radix-16 Stockham.  Each thread owns 16 points; a transform
+// uses n/16 threads; stages are radix 16, 16, ... and a last stage of radix n / 16^k (2, 4 or 8 -- the
+// thread then does 16/R butterflies).  Stage recurrence = the reference's (fft.wgsl:27-62) with the pair
+// (a, b) generalised to R inputs:  idx = s*J + j;  inputs idx + m*n/R;  outputs s*R*J + j + q*J, scaled
+// by W_n^{s*J*q} (table of processor.rs:43-49).  The first stage reads global memory directly (coalesced
+// over idx), the last one writes it directly (coalesced over idx); in between one LDS buffer, padded by
+// one element per 16, carries the exchange (conflict-free b64 writes at every stage).
+// ---------------------------------------------------------------------------
+// In-wave exchange for n = 32, 64, 128 (one radix-16 stage + one radix-R stage, R = n/16 lanes per
+// transform): the element in (lane m, register b*R + r) moves to (lane r, register b*R + m) -- an R x R
+// transpose per register group, done as log2(R) butterfly steps of `__shfl_xor` + select.  No LDS memory, no
+// barrier.  Measured 3-10 % SLOWER than the padded-LDS exchange at these sizes (ds_bpermute issue cost), so the
+// plan uses it only when asked (small_reg = 2); DPP quad-permute moves miscompiled under hipcc 7.2 (one of two
+// back-to-back moves of a float2 dropped) and are not used.
+template <int R>
+__device__ __forceinline__ void wave_transpose(v2f (&x)[16], uint32_t lane_in_group)
+{
+    static_for<0, ilog2c(R)>([&](auto s_) {
+        constexpr int sft = decltype(s_)::value;
+        const bool hi = (lane_in_group >> sft) & 1;
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q0 = decltype(q_)::value;
+            if constexpr (((q0 % R) >> sft & 1) == 0) {
+                constexpr int q1 = q0 | (1 << sft);
+                const v2f send = hi ? x[q0] : x[q1];
+                v2f recv;
+                recv.x = __shfl_xor(send.x, 1 << sft);
+                recv.y = __shfl_xor(send.y, 1 << sft);
+                if (hi) x[q0] = recv; else x[q1] = recv;
+            }
+        });
+    });
+}
+
+template <int LGN, int DIR, bool SHFL = false>
+__global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small16(const v2f *__restrict__ src,
+                                                                                  v2f *__restrict__ dst,
+                                                                                  const v2f *__restrict__ tw,
+                                                                                  uint64_t batch, float scale)
+{
+    constexpr int N = 1 << LGN;
+    constexpr int TPX = N / 16;                       // threads per transform
+    constexpr int WG = LGN <= 12 ? 256 : TPX;         // 8192 / 16384 points: one transform per 512 / 1024 threads
+    constexpr int XPW = WG / TPX;                     // transforms per workgroup
+    constexpr int NS16 = LGN / 4;        // radix-16 stages
+    constexpr int RL = 1 << (LGN % 4);   // last radix (1 = none)
+    constexpr int PADN = N + N / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f *lds = reinterpret_cast<v2f *>(smem) + (threadIdx.x / TPX) * PADN;
+    const uint32_t t = threadIdx.x % TPX;
+    const uint64_t xf = (uint64_t)blockIdx.x * XPW + threadIdx.x / TPX;
+    const bool live = xf < batch;
+    const v2f *g_in = src + xf * N;
+    v2f *g_out = dst + xf * N;
+    auto pad = [](uint32_t p) { return p + (p >> 4); };
+
+    if constexpr (SHFL && NS16 == 1 && RL > 1) {
+        // n = 32, 64, 128: radix-16 from global, wavefront shuffle exchange, radix-RL to global
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = live ? g_in[t + m * TPX] : v2f{0.f, 0.f}; });
+        fft_reg<16, DIR>(x);
+        v2f y[16];
+        static_for<0, 16>([&](auto q_) {  // stage-0 output q of thread t sits at t*16 + q; twiddle W_n^{t*q}
+            constexpr int q = decltype(q_)::value;
+            y[q] = x[brev<16>(q)];
+            if constexpr (q != 0) y[q] = cmul_tw<DIR>(y[q], tw_lookup<N>(tw, t * q));
+        });
+        wave_transpose<RL>(y, t);  // y[b*RL + m] = input m of butterfly idx = t + b*RL
+        static_for<0, 16 / RL>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            v2f z[RL];
+            static_for<0, RL>([&](auto m_) { constexpr int m = decltype(m_)::value; z[m] = y[b * RL + m]; });
+            fft_reg<RL, DIR>(z);
+            static_for<0, RL>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if (live) g_out[t + b * RL + q * 16] = z[brev<RL>(q)] * scale;  // idx + q*J, J = 16
+            });
+        });
+        return;
+    }
+    // stage 0: global -> (LDS | global)
+    {
+        constexpr bool only = (NS16 == 1 && RL == 1);
+        if (live || !only)
+            stage_bfly<16, N, DIR>([&](uint32_t i) { return live ? g_in[i] : v2f{0.f, 0.f}; },
+                                   [&](uint32_t o, v2f v) {
+                                       if constexpr (only) { if (live) g_out[o] = v * scale; }
+                                       else lds[pad(o)] = v;
+                                   },
+                                   tw, t, 1u);
+        if constexpr (only) return;
+    }
+    uint32_t J = 16;
+    // middle radix-16 stages
+    static_for<1, NS16>([&](auto s_) {
+        constexpr int st = decltype(s_)::value;
+        constexpr bool last = (st == NS16 - 1) && RL == 1;
+        __syncthreads();
+        v2f x[16];
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * (N / 16))]; });
+        if constexpr (!last) __syncthreads();
+        fft_reg<16, DIR>(x);
+        const uint32_t j = t & (J - 1), sJ = t - j;
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            v2f v = x[brev<16>(q)];
+            if constexpr (q != 0 && !last) v = cmul_tw<DIR>(v, tw_lookup<N>(tw, sJ * q));
+            const uint32_t o = sJ * 16 + j + q * J;
+            if constexpr (last) { if (live) g_out[o] = v * scale; }
+            else lds[pad(o)] = v;
+        });
+        J *= 16;
+    });
+    // last stage of radix RL < 16: 16/RL butterflies per thread, outputs straight to global
+    if constexpr (RL > 1) {
+        __syncthreads();
+        static_for<0, 16 / RL>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            stage_bfly<RL, N, DIR>([&](uint32_t i) { return lds[pad(i)]; },
+                                   [&](uint32_t o, v2f v) { if (live) g_out[o] = v * scale; }, tw, t + b * TPX, J);
+        });
+    }
+}
+
+template <int DIR>
+static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t batch, float scale,
+                                     bool shfl, hipStream_t st)
+{
+    const uint32_t n = 1u << lg_n;
+    const uint32_t wg = lg_n <= 12 ? 256 : n / 16;
+    const uint32_t xpw = wg / (n / 16);
+    const uint64_t blocks = (batch + xpw - 1) / xpw;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
+    const dim3 g((uint32_t)blocks), b(wg);
+    switch (lg_n) {
+        case 4: hipLaunchKernelGGL((k_small16<4, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 5:
+            if (shfl) hipLaunchKernelGGL((k_small16<5, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<5, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
+        case 6:
+            if (shfl) hipLaunchKernelGGL((k_small16<6, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<6, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
+        case 7:
+            if (shfl) hipLaunchKernelGGL((k_small16<7, DIR, true>), g, b, lds, st, src, dst, tw, batch, scale);
+            else hipLaunchKernelGGL((k_small16<7, DIR>), g, b, lds, st, src, dst, tw, batch, scale);
+            break;
+        case 8: hipLaunchKernelGGL((k_small16<8, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 9: hipLaunchKernelGGL((k_small16<9, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 10: hipLaunchKernelGGL((k_small16<10, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 11: hipLaunchKernelGGL((k_small16<11, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 12: hipLaunchKernelGGL((k_small16<12, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 13: hipLaunchKernelGGL((k_small16<13, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 14: hipLaunchKernelGGL((k_small16<14, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                          bool wave_shuffle, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    uint32_t lg_n = 0;
+    while ((1u << lg_n) < n) ++lg_n;
+    return dir == FWD ? launch_small16_dir<FWD>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st)
+                      : launch_small16_dir<INV>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st);
+}
+
+hipError_t setup_small_kernels()
+{
+    // 8192 / 16384-point transforms need 68 / 136 KiB of dynamic LDS
+    const void *ks[4] = {reinterpret_cast<const void *>(&k_small16<13, FWD>), reinterpret_cast<const void *>(&k_small16<13, INV>),
+                         reinterpret_cast<const void *>(&k_small16<14, FWD>), reinterpret_cast<const void *>(&k_small16<14, INV>)};
+    for (int i = 0; i < 4; ++i) {
+        const int n = i < 2 ? 8192 : 16384;
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (n + n / 16) * 8);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+
+// ---------------------------------------------------------------------------
+// elementwise: normalize (normalize.wgsl:9-12), synthetic fill, calibration copy
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale(const v4f *a, v4f *b, uint64_t n_vec,
+                                               float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) b[i] = a[i] * scale;
+}
+
+__global__ __launch_bounds__(256) void k_scale_tail(const v2f *a, v2f *b, uint64_t first,
+                                                    uint64_t n, float scale)
+{
+    const uint64_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i] * scale;
+}
+
+static uint32_t stream_grid(uint64_t work_items)
+{
+    uint64_t blocks = (work_items + 255) / 256;
+    const uint64_t cap = 256 * 8 * 4;  // ~8192 blocks, grid-stride the rest
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st)
+{
+    if (n_samples == 0) return hipSuccess;
+    const uint64_t n_vec = n_samples / 2;
+    if (n_vec)
+        hipLaunchKernelGGL(k_scale, dim3(stream_grid(n_vec)), dim3(256), 0, st, reinterpret_cast<const v4f *>(a),
+                           reinterpret_cast<v4f *>(b), n_vec, scale);
+    if (n_samples & 1)
+        hipLaunchKernelGGL(k_scale_tail, dim3(1), dim3(256), 0, st, a, b, n_vec * 2, n_samples, scale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_fill(v2f *__restrict__ dst, uint64_t seed, uint64_t g0, uint64_t n_samples,
+                                              float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += stride)
+        dst[i] = gen_sample(seed, g0 + i, scale);
+}
+
+hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st)
+{
+    if (n_samples == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill, dim3(stream_grid(n_samples)), dim3(256), 0, st, dst, seed, g0, n_samples, scale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t n_vec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) b[i] = a[i];
+}
+
+hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st)
+{
+    const uint64_t n_vec = bytes / 16;
+    if (n_vec == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy, dim3(stream_grid(n_vec)), dim3(256), 0, st, reinterpret_cast<const v4f *>(src),
+                       reinterpret_cast<v4f *>(dst), n_vec);
+    return hipGetLastError();
+}
+
+}  // namespace fwa
