@@ -176,16 +176,16 @@ def main():
                        "scratch_bytes": plan.get("scratch_bytes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_mix_1m (every launch of one fwa_plan_exec; pass-1 + pass-2 tiles side by side)",
+                         "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group of transforms, two chains)",
                          "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),
-                         # one exec = `launches` k_mix_1m launches on `chains` concurrent internal streams; each
-                         # launch carries pass 1 of `group` transforms and pass 2 of `group` others = `group`
-                         # transforms' worth of algorithmic bytes.  rocprofv3's average k_mix_1m duration must
-                         # equal avg_launch_us (profiles/round1/e_final_kernel_stats.csv: 82.6 us).
+                         # one exec = `launches` kernel launches (k_p1_1m, k_p2_1m alternating per group) on `chains`
+                         # concurrent internal streams; a launch carries one pass of `group` transforms = half of
+                         # their algorithmic bytes.  rocprofv3's mean duration over k_p1_1m and k_p2_1m launches must
+                         # equal avg_launch_us.
                          "per_launch": {"launches": plan.get("launches_per_exec"), "chains": plan.get("streams"),
                                         "avg_launch_us": ev_ms * 1e3 * plan.get("streams") / max(1, plan.get("launches_per_exec")),
-                                        "algorithmic_bytes": ALGO_BYTES_PER_SAMPLE * n * plan.get("group"),
-                                        "achieved_GBps_one_launch": ALGO_BYTES_PER_SAMPLE * n * plan.get("group") /
+                                        "algorithmic_bytes": ALGO_BYTES_PER_SAMPLE * n * plan.get("group") // (1 if plan.get("mix") else 2),
+                                        "achieved_GBps_one_launch": ALGO_BYTES_PER_SAMPLE * n * plan.get("group") / (1 if plan.get("mix") else 2) /
                                         (ev_ms * 1e-3 * plan.get("streams") / max(1, plan.get("launches_per_exec"))) / 1e9},
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
                          "copy_ceiling_GBps_same_run": copy_gbps},

@@ -81,7 +81,7 @@ struct fwa_plan {
     uint64_t leaf_batch = 0;            // sub-transforms the 2^20 pipeline / LDS kernel runs per exec
     // 2^20 pipeline
     v2f *ring = nullptr;
-    int64_t group = 8;             // transforms per launch pair
+    int64_t group = 16;            // transforms per launch pair (measured best with unmixed launches, two chains)
     int64_t n_streams = 2;         // internal streams the groups alternate over
     uint64_t ring_slots = 0;
     uint64_t slot_bytes = 0;
@@ -90,7 +90,8 @@ struct fwa_plan {
     int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
     int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
-    int64_t mix = 1;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
+    int64_t mix = 0;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
+                                   // (same-run A/B, profiles/round1/f_mixed_vs_unmixed.txt: unmixed 16x2 21.4 ms, mixed 8x2 22.6 ms)
     int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels_1m.hip)
     int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
     std::vector<hipStream_t> istreams;
