@@ -921,7 +921,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         return build_pipeline(plan);
     }
     if (k == "policy") {
-        if (value < 0 || value > 4) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "policy out of range");
+        if (value < 0 || value > 7) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "policy out of range");
         plan->policy = value;
         return FWA_OK;
     }

@@ -229,7 +229,10 @@ __global__ __launch_bounds__(512, 4) void k_mix_1m(const v2f *__restrict__ p1_sr
     // tile on four XCDs and every pass-2 tile on the other four; bit 3 instead gives each XCD both roles
     // (dbg & 128 selects the old split, for A/B timing).
     uint32_t role, idx;
-    if (dbg & 128) { role = blockIdx.x & 1; idx = blockIdx.x >> 1; }
+    if (dbg & 256) {  // pass-2 tiles first, then pass-1 tiles: one HBM direction at a time inside the launch
+        const uint32_t n2w = n2 * 64;
+        if (blockIdx.x < n2w) { role = 1; idx = blockIdx.x; } else { role = 0; idx = blockIdx.x - n2w; }
+    } else if (dbg & 128) { role = blockIdx.x & 1; idx = blockIdx.x >> 1; }
     else { role = (blockIdx.x >> 3) & 1; idx = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7); }
     const bool skel = (dbg & 32) != 0;  // timing-only: memory skeleton
     const uint32_t tile = idx & 63;
@@ -386,13 +389,14 @@ __global__ __launch_bounds__(512, 4) void k_fused_1m(v2f *data, const v2f *__res
 //             (Guideline 16 form "every store of the handed-off bytes sc1, drained, then counter;
 //              every load of them an sc1 load after the poll + workgroup barrier")
 //   policy 2: as 1 with sc0|sc1 stores      policy 3: as 1 without nt      policy 4: nt only, fences kept
-constexpr int N_POLICIES = 5;
+constexpr int N_POLICIES = 8;  // 5..7: more ring-side variants (two-launch kernels only)
 
 template <int DIR>
 static const void *fused_kernel(int policy)
 {
     switch (policy) {
-        case 1: return reinterpret_cast<const void *>(&k_fused_1m<DIR, false, AUX_NT, AUX_SC1, AUX_SC1, AUX_NT>);
+        case 1: case 5: case 6: case 7:
+            return reinterpret_cast<const void *>(&k_fused_1m<DIR, false, AUX_NT, AUX_SC1, AUX_SC1, AUX_NT>);
         case 2: return reinterpret_cast<const void *>(&k_fused_1m<DIR, false, AUX_NT, AUX_SC1 | 1, AUX_SC1, AUX_NT>);
         case 3: return reinterpret_cast<const void *>(&k_fused_1m<DIR, false, AUX_DEFAULT, AUX_SC1, AUX_SC1, AUX_DEFAULT>);
         case 4: return reinterpret_cast<const void *>(&k_fused_1m<DIR, true, AUX_NT, AUX_DEFAULT, AUX_DEFAULT, AUX_NT>);
@@ -407,6 +411,9 @@ static const void *p1_kernel(int policy)
         case 2: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_NT, AUX_SC1 | 1>);
         case 3: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_DEFAULT, AUX_SC1>);
         case 4: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_NT, AUX_DEFAULT>);
+        case 5: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_NT, AUX_SC1>);
+        case 6: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_NT, AUX_SC1 | AUX_NT>);
+        case 7: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_NT, AUX_NT>);
         default: return reinterpret_cast<const void *>(&k_p1_1m<DIR, AUX_DEFAULT, AUX_DEFAULT>);
     }
 }
@@ -415,6 +422,7 @@ static const void *p2_kernel(int policy)
 {
     switch (policy) {
         case 1: case 2: case 4: return reinterpret_cast<const void *>(&k_p2_1m<DIR, AUX_DEFAULT, AUX_NT>);
+        case 5: case 6: case 7: return reinterpret_cast<const void *>(&k_p2_1m<DIR, AUX_NT, AUX_NT>);
         default: return reinterpret_cast<const void *>(&k_p2_1m<DIR, AUX_DEFAULT, AUX_DEFAULT>);
     }
 }
@@ -423,7 +431,8 @@ template <int DIR>
 static const void *mix_kernel(int policy)
 {
     switch (policy) {
-        case 1: return reinterpret_cast<const void *>(&k_mix_1m<DIR, AUX_NT, AUX_SC1, AUX_DEFAULT, AUX_NT>);
+        case 1: case 5: case 6: case 7:
+            return reinterpret_cast<const void *>(&k_mix_1m<DIR, AUX_NT, AUX_SC1, AUX_DEFAULT, AUX_NT>);
         case 2: return reinterpret_cast<const void *>(&k_mix_1m<DIR, AUX_NT, AUX_SC1 | 1, AUX_DEFAULT, AUX_NT>);
         case 3: return reinterpret_cast<const void *>(&k_mix_1m<DIR, AUX_DEFAULT, AUX_SC1, AUX_DEFAULT, AUX_DEFAULT>);
         case 4: return reinterpret_cast<const void *>(&k_mix_1m<DIR, AUX_NT, AUX_DEFAULT, AUX_DEFAULT, AUX_NT>);

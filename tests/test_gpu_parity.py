@@ -193,7 +193,7 @@ def test_config_c2_n1m(gpu, oracle, batch, path, a, b):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_n1m_cache_policies_are_bit_identical(gpu, oracle, policy):
     """Cache-policy variants (write-through / non-temporal accesses, with or without fences) change how
     workgroups hand the intermediate over, never the arithmetic: every variant of both pipelines must
