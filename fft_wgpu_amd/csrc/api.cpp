@@ -771,12 +771,14 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.in = a + g * G * N; ta.out = slab; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;
                 ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / 16);
+                ta.flags = (uint32_t)plan->dbg | (plan->policy ? (1u << 8) : 0);  // first pass: user buffer -> ring
                 e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
                 if (e != hipSuccess) break;
                 if (three) {  // pass B, in place in the slab
                     ta.in = slab; ta.out = slab; ta.tw = plan->tw_l[1]; ta.tw_lo = plan->tw_lo_b; ta.tw_hi = plan->tw_hi_b;
                     ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1;
                     ta.tile_count = (uint32_t)(N3 / 16);
+                    ta.flags = (uint32_t)plan->dbg | (plan->policy ? (2u << 8) : 0);  // middle pass: ring -> ring
                     e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[1], ta, cnt, s);
                     if (e != hipSuccess) break;
                 }
@@ -789,6 +791,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.in_st = 16 * (N / N1); ta.out_st = 16; ta.tile_count = (uint32_t)(N1 / 16);
                 if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
                 else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
+                ta.flags = (uint32_t)plan->dbg | (plan->policy ? (3u << 8) : 0);  // last pass: ring -> user buffer
                 e = fwa::launch_tile16(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, cnt, s);
             }
             if (e != hipSuccess) break;

@@ -27,7 +27,8 @@ struct TileArgs {
     uint64_t out_stride;              // ROWS_T: element stride between consecutive outputs of a row
     uint32_t d1_count, tile_count;    // blockIdx.x = (b*d1_count + d1)*tile_count + tile
     float scale;
-    uint32_t flags;                   // timing-only ablations (0 in the product path)
+    uint32_t flags;                   // bit 0: timing-only ablation (twiddles = 1); bits 8-9: cache policy role
+                                      // (0 default, 1 first pass, 2 middle pass, 3 last pass)
 };
 
 // 16 FFTs of length 2^lg_l per workgroup along one axis (kernels_tiled.hip: k_tile16); blocks = batch*d1_count*tile_count

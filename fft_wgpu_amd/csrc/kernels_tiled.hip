@@ -14,7 +14,10 @@ namespace fwa {
 //         the exchange re-maps threads, and output element o of row c goes to out + o*out_stride + c
 //         (16 adjacent rows = one 128-B segment): the transposed store that restores natural order.
 // ---------------------------------------------------------------------------
-template <int LGL, int DIR, int MODE, bool BUF>
+// POL: cache policy of the global accesses (measured on the 2^20 pipeline: `nt` on user-buffer accesses and
+// write-through `sc1` ring stores): 0 = default everywhere, 1 = first pass (user buffer -> ring: loads nt,
+// stores sc1), 2 = ring -> ring (stores sc1), 3 = last pass (ring -> user buffer: stores nt)
+template <int LGL, int DIR, int MODE, bool BUF, int POL>
 __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
 {
     constexpr int L = 1 << LGL;
@@ -22,6 +25,7 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     constexpr int NS16 = LGL / 4;
     constexpr int RL = 1 << (LGL % 4);
     constexpr int PADN = L + L / 16;
+    constexpr int AOUT = (POL == 1 || POL == 2) ? AUX_SC1 : (POL == 3 ? AUX_NT : AUX_DEFAULT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f *lds_all = reinterpret_cast<v2f *>(smem);
     auto pad = [](uint32_t p) { return p + (p >> 4); };
@@ -54,7 +58,7 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
         v2f x[16];
         static_for<0, 16>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
-            if constexpr (BUF) x[m] = buf_load<AUX_DEFAULT>(rin, vin, m * sin_step);
+            if constexpr (BUF) x[m] = buf_load<(POL == 1 ? AUX_NT : AUX_DEFAULT)>(rin, vin, m * sin_step);
             else x[m] = (MODE == TILE_COLS) ? in[(uint64_t)(t0 + m * (L / 16)) * a.pitch + c0]
                                             : in[(uint64_t)c0 * a.pitch + t0 + m * (L / 16)];
         });
@@ -87,11 +91,11 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
         const uint32_t o = t + m * TPX;
         if constexpr (MODE == TILE_COLS) {
             v = cmul_tw<DIR>(v, cmul(pa[m >> 2], pb[m & 3])) * a.scale;
-            if constexpr (BUF) buf_store<AUX_DEFAULT>(v, rout, (t * pitch32 + cB) * 8, m * (uint32_t)TPX * pitch32 * 8);
+            if constexpr (BUF) buf_store<AOUT>(v, rout, (t * pitch32 + cB) * 8, m * (uint32_t)TPX * pitch32 * 8);
             else out[(uint64_t)o * a.pitch + cB] = v;
         } else {
             v = v * a.scale;
-            if constexpr (BUF) buf_store<AUX_DEFAULT>(v, rout, (t * ostride32 + cB) * 8, m * (uint32_t)TPX * ostride32 * 8);
+            if constexpr (BUF) buf_store<AOUT>(v, rout, (t * ostride32 + cB) * 8, m * (uint32_t)TPX * ostride32 * 8);
             else out[(uint64_t)o * a.out_stride + cB] = v;
         }
     };
@@ -137,22 +141,32 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     }
 }
 
-template <int DIR, int MODE, bool BUF>
-static const void *tile16_kernel_b(uint32_t lg_l)
+template <int DIR, int MODE, bool BUF, int POL>
+static const void *tile16_kernel_p(uint32_t lg_l)
 {
     switch (lg_l) {
-        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE, BUF>);
-        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE, BUF>);
-        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE, BUF>);
-        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE, BUF>);
-        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE, BUF>);
+        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE, BUF, POL>);
+        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE, BUF, POL>);
+        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE, BUF, POL>);
+        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE, BUF, POL>);
+        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE, BUF, POL>);
         default: return nullptr;
     }
 }
+// COLS passes come as first (policy 1) or middle (2) pass, ROWS_T is always the last (3); the 64-bit-pointer
+// fallback (BUF = false, only above 4-GiB tiles) has no policy bits.  pol 0 = default policies (A/B timing).
 template <int DIR, int MODE>
-static const void *tile16_kernel(uint32_t lg_l, bool buf = true)
+static const void *tile16_kernel(uint32_t lg_l, bool buf, int pol)
 {
-    return buf ? tile16_kernel_b<DIR, MODE, true>(lg_l) : tile16_kernel_b<DIR, MODE, false>(lg_l);
+    if (!buf) return tile16_kernel_p<DIR, MODE, false, 0>(lg_l);
+    if constexpr (MODE == TILE_COLS) {
+        if (pol == 1) return tile16_kernel_p<DIR, MODE, true, 1>(lg_l);
+        if (pol == 2) return tile16_kernel_p<DIR, MODE, true, 2>(lg_l);
+        return tile16_kernel_p<DIR, MODE, true, 0>(lg_l);
+    } else {
+        if (pol == 3) return tile16_kernel_p<DIR, MODE, true, 3>(lg_l);
+        return tile16_kernel_p<DIR, MODE, true, 0>(lg_l);
+    }
 }
 static size_t tile16_lds(uint32_t lg_l) { return (size_t)16 * ((1u << lg_l) + (1u << lg_l) / 16) * sizeof(v2f); }
 
@@ -161,10 +175,15 @@ hipError_t prepare_tile16(uint32_t lg_l)
 {
     const size_t lds = tile16_lds(lg_l);
     if (lds <= 65536) return hipSuccess;
-    const void *ks[8] = {tile16_kernel<FWD, TILE_COLS>(lg_l, true),  tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true),
-                         tile16_kernel<INV, TILE_COLS>(lg_l, true),  tile16_kernel<INV, TILE_ROWS_T>(lg_l, true),
-                         tile16_kernel<FWD, TILE_COLS>(lg_l, false), tile16_kernel<FWD, TILE_ROWS_T>(lg_l, false),
-                         tile16_kernel<INV, TILE_COLS>(lg_l, false), tile16_kernel<INV, TILE_ROWS_T>(lg_l, false)};
+    const void *ks[14] = {
+        tile16_kernel<FWD, TILE_COLS>(lg_l, true, 0),  tile16_kernel<FWD, TILE_COLS>(lg_l, true, 1),
+        tile16_kernel<FWD, TILE_COLS>(lg_l, true, 2),  tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true, 0),
+        tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true, 3), tile16_kernel<FWD, TILE_COLS>(lg_l, false, 0),
+        tile16_kernel<FWD, TILE_ROWS_T>(lg_l, false, 0),
+        tile16_kernel<INV, TILE_COLS>(lg_l, true, 0),  tile16_kernel<INV, TILE_COLS>(lg_l, true, 1),
+        tile16_kernel<INV, TILE_COLS>(lg_l, true, 2),  tile16_kernel<INV, TILE_ROWS_T>(lg_l, true, 0),
+        tile16_kernel<INV, TILE_ROWS_T>(lg_l, true, 3), tile16_kernel<INV, TILE_COLS>(lg_l, false, 0),
+        tile16_kernel<INV, TILE_ROWS_T>(lg_l, false, 0)};
     for (const void *k : ks) {
         if (!k) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -183,7 +202,7 @@ static hipError_t launch_tile16_mode(uint32_t lg_l, const TileArgs &a, uint64_t 
     const uint64_t span = (MODE == TILE_COLS) ? L * a.pitch * 8 + 128
                                               : ((16 * a.pitch + L) * 8 > (L * a.out_stride + 16) * 8 ? (16 * a.pitch + L) * 8
                                                                                                     : (L * a.out_stride + 16) * 8);
-    const void *k = tile16_kernel<DIR, MODE>(lg_l, span < (1ull << 32));
+    const void *k = tile16_kernel<DIR, MODE>(lg_l, span < (1ull << 32), (int)(a.flags >> 8) & 3);
     if (!k) return hipErrorInvalidValue;
     TileArgs copy = a;
     void *args[] = {&copy};
