@@ -574,9 +574,10 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
             st = level((uint64_t)fft_len >> p->lf[0], &p->tw_lo_b, &p->tw_hi_b);
             if (st) return bail(st);
         }
-        // intermediate of a group of transforms lives in a cache-sized ring slab (64 MiB per chain)
+        // intermediate of a group of transforms lives in a ring slab of 128 MiB per chain (two chains = the
+        // 256-MiB Infinity Cache; group sweep in profiles/round1/h_tiled_group_sweep.jsonl)
         const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
-        p->group = (int64_t)((64ull << 20) / per);
+        p->group = (int64_t)((128ull << 20) / per);
         if (p->group < 1) p->group = 1;
         st = build_pipeline(p);
         if (st) return bail(st);
