@@ -6,6 +6,10 @@ generated on the device, resident in HBM before the clock starts).  One process 
 shard as independent slabs (no data-path collective), so scaling is "weak": every rank runs the
 full 4096-transform slab (config C4 = 4096 per GPU x 8).
 
+Launch: `python bench.py --gpus N` starts its own N ranks (child processes, started before anything touches a
+GPU) when WORLD_SIZE is not set; under torchrun it uses the environment it is given.  It refuses to run with
+fewer visible devices than --gpus.
+
 Timing: K steps inside barrier + torch.cuda.synchronize() brackets, wall clock, MAX over ranks.
 Because a forward FFT multiplies the RMS by 2^10 and `proc` works in place, the K steps run in
 chunks of <= 8 with the input regenerated (at scale 2^-40) between chunks, outside the brackets,
@@ -38,6 +42,30 @@ def usable_cores():
     return n
 
 
+def self_launch(args):
+    """No launcher environment and --gpus N > 1: start N ranks of this script (one process per GPU) and relay
+    their exit status.  Runs before any HIP call; torch.cuda.device_count() does not initialise the GPU."""
+    import socket
+    import subprocess
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} device(s) visible; refusing to "
+                         f"report a {args.gpus}-GPU figure from fewer GPUs")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,14 +79,19 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # never returns
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -71,6 +104,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import fft_wgpu_amd as fw
+    from fft_wgpu_amd import sharding
 
     got = fw.prepare_gpu(local_rank)
     if got is None:
@@ -85,7 +119,8 @@ def main():
     if args.streams:
         plan.set("streams", args.streams)
     enc = dev.create_command_encoder()   # the stream every kernel of the timed region is launched on
-    first = rank * batch                 # this rank's slab of the global batch (sharding.slab with equal slabs)
+    first, last = sharding.slab(batch * world, rank, world)   # this rank's slab of the global batch (config C4)
+    assert last - first == batch
 
     def regen():
         dev.fill_synthetic(buf, n, first_transform=first, scale=2.0 ** -40, encoder=enc)
@@ -162,6 +197,13 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{n}x{batch}")
             except Exception:
                 traffic = None
+        launches = max(1, plan.get("launches_per_exec"))
+        chains = max(1, plan.get("streams"))
+        group = plan.get("group")
+        # one exec = `launches` kernel launches (k_p1_1m then k_p2_1m per group of transforms) on `chains` concurrent
+        # internal streams; a launch carries one pass over `group` transforms = half of their algorithmic bytes.
+        avg_launch_us = ev_ms * 1e3 * chains / launches
+        launch_bytes = ALGO_BYTES_PER_SAMPLE * n * group // 2
         line = {
             "metric": "Gsamples/s, 1-D c2c fp32 forward FFT N=2^20 batch=4096 per GPU",
             "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,23 +212,19 @@ def main():
             "config": {"workload": f"1-D c2c fp32 FFT N={n} batch={batch} per GPU (BASELINE.json configs[2]"
                                    f"{'; configs[3] shape' if world > 1 else ''})",
                        "fft_len": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective",
-                       "plan_path": plan.get("path"), "group": plan.get("group"), "streams": plan.get("streams"),
-                       "mixed_launches": plan.get("mix"), "cache_policy": plan.get("policy"),
-                       "launches_per_step": plan.get("launches_per_exec"),
+                       "plan_path": plan.get("path"), "group": group, "streams": chains,
+                       "tile_w": plan.get("tile_w"), "launches_per_step": launches,
                        "scratch_bytes": plan.get("scratch_bytes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group of transforms, two chains)",
+                         "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group "
+                                   "of transforms, alternating over the chains)",
                          "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),
-                         # one exec = `launches` kernel launches (k_p1_1m, k_p2_1m alternating per group) on `chains`
-                         # concurrent internal streams; a launch carries one pass of `group` transforms = half of
-                         # their algorithmic bytes.  rocprofv3's mean duration over k_p1_1m and k_p2_1m launches must
-                         # equal avg_launch_us.
-                         "per_launch": {"launches": plan.get("launches_per_exec"), "chains": plan.get("streams"),
-                                        "avg_launch_us": ev_ms * 1e3 * plan.get("streams") / max(1, plan.get("launches_per_exec")),
-                                        "algorithmic_bytes": ALGO_BYTES_PER_SAMPLE * n * plan.get("group") // (1 if plan.get("mix") else 2),
-                                        "achieved_GBps_one_launch": ALGO_BYTES_PER_SAMPLE * n * plan.get("group") / (1 if plan.get("mix") else 2) /
-                                        (ev_ms * 1e-3 * plan.get("streams") / max(1, plan.get("launches_per_exec"))) / 1e9},
+                         # rocprofv3's mean duration over the k_p1_1m and k_p2_1m launches must equal avg_launch_us
+                         # (launches of different chains overlap: sum of durations / chains = exec time)
+                         "per_launch": {"launches": launches, "chains": chains, "avg_launch_us": avg_launch_us,
+                                        "algorithmic_bytes": launch_bytes,
+                                        "achieved_GBps_one_launch": launch_bytes / (avg_launch_us * 1e-6) / 1e9},
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
                          "copy_ceiling_GBps_same_run": copy_gbps},
             "cpu_baseline": cpu,

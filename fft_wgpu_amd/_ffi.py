@@ -37,6 +37,8 @@ _SIGNATURES = {
     "fwa_device_count": (_I32, [ctypes.POINTER(_I32)]),
     "fwa_ctx_create": (_I32, [_I32, _PP]),
     "fwa_ctx_destroy": (_I32, [_P]),
+    "fwa_ctx_synchronize": (_I32, [_P]),
+    "fwa_ctx_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "fwa_ctx_device_info": (_I32, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_I32),
                                    ctypes.POINTER(_U64)]),
     "fwa_stream_create": (_I32, [_P, _PP]),

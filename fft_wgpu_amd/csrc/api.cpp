@@ -2,23 +2,59 @@
 //
 // Mirrors the plan objects of reference src/processor.rs (Forward :7-159,
 // Inverse :231-341, Normalize :409-505, Onlyinverse :566-670) without any of
-// its wgpu plumbing: a plan owns its twiddle tables and scratch, exec only
-// enqueues kernels on the caller's stream and allocates nothing.
+// its wgpu plumbing: a plan owns (or shares through the context's plan cache)
+// its twiddle tables and scratch, exec only enqueues kernels on the caller's
+// stream and allocates nothing.
 #include "../../include/fft_wgpu_amd.h"
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "kernels.h"
 
 using fwa::v2f;
+
+enum fwa_path : int64_t {
+    PATH_SMALL = 0,       // n <= 16384: one launch (k_tiny / k_small16 / k_lds_small)
+    PATH_TWOPASS_1M = 1,  // n = 2^20: k_p1_1m + k_p2_1m per group of transforms
+    PATH_R2_GLOBAL = 2,   // the reference recurrence literally, one launch per stage (forced only)
+    PATH_NORMALIZE = 3,
+    PATH_IDENTITY = 4,    // n = 1
+    PATH_RING_1M = 5,     // n = 2^20: the same two passes as ONE persistent launch with a small ring (k_ring_1m)
+    PATH_TILED = 7,       // n = N1*N2[*N3], each 64..1024: 2-3 k_tile passes
+};
+
+namespace {
+
+// Device tables of one transform length, shared by every plan of that length on a context (plan cache):
+// tables hold forward twiddles only (the inverse conjugates on use), so all plan kinds share them.
+struct Tables {
+    v2f *tw_half = nullptr;   // n/2 entries, processor.rs:43-49 (small / literal paths)
+    v2f *tw_inner = nullptr;  // 2^20 path: [k1][n'] = W_1024^{n' k1}
+    v2f *tw_outer[2] = {nullptr, nullptr};  // 2^20 path, tile width 16 / 32: per tile A[32][W], B[32][W]
+    v2f *tw_l[3] = {nullptr, nullptr, nullptr};  // tiled path: per-factor W_L tables
+    v2f *tw_lo1 = nullptr, *tw_hi1 = nullptr;    // four-step tables of pass A (domain n)
+    v2f *tw_lo_b = nullptr, *tw_hi_b = nullptr;  // four-step tables of pass B (domain N2*N3)
+    ~Tables()
+    {
+        for (v2f *t : {tw_half, tw_inner, tw_outer[0], tw_outer[1], tw_l[0], tw_l[1], tw_l[2], tw_lo1, tw_hi1, tw_lo_b,
+                       tw_hi_b})
+            if (t) (void)hipFree(t);
+    }
+};
+
+}  // namespace
 
 struct fwa_ctx {
     int device = -1;
@@ -26,6 +62,11 @@ struct fwa_ctx {
     mutable std::string err;
     bool setup_1m_done = false;
     bool setup_small_done = false;
+    // plan cache: (fft_len, path, factor signature) -> tables; ring allocations of destroyed plans by size
+    std::map<std::tuple<uint32_t, int64_t, uint32_t>, std::shared_ptr<Tables>> tables;
+    std::multimap<uint64_t, void *> free_rings;
+    uint64_t free_ring_bytes = 0;
+    int64_t n_table_builds = 0, n_table_hits = 0, n_ring_allocs = 0, n_ring_reuses = 0, last_plan_create_us = 0;
 };
 struct fwa_stream {
     fwa_ctx *ctx = nullptr;
@@ -43,17 +84,6 @@ struct fwa_event {
     hipEvent_t e = nullptr;
 };
 
-enum fwa_path : int64_t {
-    PATH_LDS_SMALL = 0,
-    PATH_TWOPASS_1M = 1,
-    PATH_R2_GLOBAL = 2,
-    PATH_NORMALIZE = 3,
-    PATH_IDENTITY = 4,
-    PATH_FUSED_1M = 5,  // in-place persistent pipeline, one launch per exec
-    PATH_TILED = 7,     // n = N1*N2[*N3], each 64..1024: 2-3 k_tile16 passes (default for 2^15..2^19, 2^21..2^30)
-    PATH_SPLIT = 6,     // n = R1*R2*M: strided register-radix passes + fast sub-transforms (M = 2^20 or 4096) + permute
-};
-
 struct fwa_plan {
     fwa_ctx *ctx = nullptr;
     int32_t kind = 0;
@@ -66,37 +96,26 @@ struct fwa_plan {
     bool second_owned = false;
     int64_t path = PATH_R2_GLOBAL;
     bool frozen = false;           // first exec done -> tunables locked
-    // tables (device)
-    v2f *tw_half = nullptr;        // n/2 entries, processor.rs:43-49
-    v2f *tw_inner = nullptr;       // 2^20 path: [k1][n'] = W_1024^{n' k1}
-    v2f *tw_outer = nullptr;       // 2^20 path: per tile A[32][16], B[32][16]
-    // tiled path (PATH_TILED): log2 of the factors (lf[2] = 0 for two factors), per-factor W_L tables,
-    // four-step tables of pass A (domain n) and pass B (domain N2*N3)
-    uint32_t lf[3] = {0, 0, 0};
-    v2f *tw_l[3] = {nullptr, nullptr, nullptr};
-    v2f *tw_lo_b = nullptr, *tw_hi_b = nullptr;
-    // split path (PATH_SPLIT)
-    uint32_t r1 = 1, r2 = 1, leaf = 0;  // n = r1 * r2 * leaf
-    v2f *tw_lo1 = nullptr, *tw_hi1 = nullptr, *tw_lo2 = nullptr, *tw_hi2 = nullptr;
-    uint64_t leaf_batch = 0;            // sub-transforms the 2^20 pipeline / LDS kernel runs per exec
-    // 2^20 pipeline
+    std::shared_ptr<Tables> tb;    // shared through ctx->tables
+    v2f *tw_half_private = nullptr;  // forced literal path on a size whose cached tables have no n/2 table
+    uint32_t lf[3] = {0, 0, 0};    // tiled path: log2 of the factors (lf[2] = 0 for two factors)
+    // pipeline state (two-pass 2^20 and tiled paths): groups of transforms alternate over internal streams
     v2f *ring = nullptr;
-    int64_t group = 16;            // transforms per launch pair (measured best with unmixed launches, two chains)
-    int64_t n_streams = 2;         // internal streams the groups alternate over
-    uint64_t ring_slots = 0;
-    uint64_t slot_bytes = 0;
-    // fused 2^20 pipeline
-    uint32_t *fused_ctl = nullptr;
-    int64_t depth = 4;             // pass-2 tiles of transform t-depth interleave with pass-1 tiles of t
-    int64_t wgs = 0;               // persistent workgroups (0 = 2 per CU)
+    uint64_t ring_bytes = 0;
+    int64_t group = 16;            // transforms per launch
+    int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
+    int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
+    int64_t cw = 16;               // tiled path: FFTs per workgroup (32 where the kernel supports it)
+    int64_t xcd_swizzle = 1;       // XCD-aware block -> tile mapping of the pipelined paths
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
-    int64_t mix = 0;               // 1: each launch carries pass-1 tiles of group g and pass-2 tiles of group g-1
-                                   // (same-run A/B, profiles/round1/f_mixed_vs_unmixed.txt: unmixed 16x2 21.4 ms, mixed 8x2 22.6 ms)
-    int64_t policy = 1;            // cache-policy variant of the 2^20 kernels (kernels_1m.hip)
-    int64_t dbg = 0;               // timing-only ablation switches of k_fused_1m (results wrong when != 0)
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
+    // persistent 2^20 pipeline (PATH_RING_1M)
+    uint32_t *ring_ctl = nullptr;  // ticket, error word, per-transform hand-off counters
+    int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
+    int64_t ring_slots = 12;       // transforms of intermediate kept (>= depth + 1)
+    int64_t wgs = 512;             // persistent workgroups (2 per CU)
 };
 
 namespace {
@@ -122,6 +141,14 @@ int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t st 
         if (e_ != hipSuccess) return fail_hip((ctx), e_, #call); \
     } while (0)
 
+// Every entry point that touches the device makes the context's device current first: with one context per
+// device in one process work must not land on whichever device was used last.
+#define USE_DEVICE(ctx)                                                             \
+    do {                                                                            \
+        int cur_ = -1;                                                              \
+        if (hipGetDevice(&cur_) != hipSuccess || cur_ != (ctx)->device) HIP_TRY((ctx), hipSetDevice((ctx)->device)); \
+    } while (0)
+
 bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
 uint32_t ilog2(uint32_t n)
 {
@@ -131,17 +158,18 @@ uint32_t ilog2(uint32_t n)
 }
 
 // Path and per-pass FFT lengths (log2) for a transform length; shared by fwa_plan_create and fwa_describe_path.
-int64_t choose_path(uint32_t n, uint32_t lf[3])
+// `batch` matters only at n = 2^20: below FEW_1M transforms the two-pass pipeline launches too few workgroups
+// (32-64 per transform) for 256 CUs, and the three-pass tiled form (thousands of small tiles) is faster.
+constexpr uint64_t FEW_1M = 4;
+int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
 {
     lf[0] = lf[1] = lf[2] = 0;
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
-    if (n <= 16384) { lf[0] = lg; return PATH_LDS_SMALL; }
-    if (n == (1u << 20)) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
+    if (n <= 16384) { lf[0] = lg; return PATH_SMALL; }
+    if (n == (1u << 20) && batch >= FEW_1M) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
-        // factors of 64..1024 each.  Tiles of 512/1024-point FFTs leave one or two workgroups per CU and run
-        // slower per pass than three passes of <= 256-point tiles (measured: 2^18 as 512x512 3.0 ms vs
-        // 64x64x64 2.3 ms per 2^28 samples), so two factors only while both stay <= 512
+        // factors of 64..1024 each: two while both stay <= 512, three otherwise (re-tunable: key "factors")
         const uint32_t nf = lg <= 17 ? 2 : 3;
         for (uint32_t i = 0; i < nf; ++i) lf[i] = lg / nf + (i >= nf - lg % nf ? 1 : 0);
         return PATH_TILED;
@@ -166,51 +194,264 @@ int32_t upload_table(fwa_ctx *ctx, const std::vector<v2f> &h, v2f **d)
     return FWA_OK;
 }
 
-hipStream_t raw(fwa_stream *s) { return s ? s->s : nullptr; }
-
-void release_pipeline(fwa_plan *p)
+int32_t upload_half_table(fwa_ctx *ctx, uint32_t n, v2f **d)
 {
-    for (auto s : p->istreams) (void)hipStreamDestroy(s);
-    for (auto e : p->idone) (void)hipEventDestroy(e);
-    p->istreams.clear();
-    p->idone.clear();
-    if (p->ev_fork) { (void)hipEventDestroy(p->ev_fork); p->ev_fork = nullptr; }
-    if (p->ring) { (void)hipFree(p->ring); p->ring = nullptr; }
-    if (p->fused_ctl) { (void)hipFree(p->fused_ctl); p->fused_ctl = nullptr; }
+    std::vector<v2f> h(n / 2);
+    for (uint32_t k = 0; k < n / 2; ++k) h[k] = tw_f64(k, n);
+    return upload_table(ctx, h, d);
 }
 
-// Allocate the scratch ring and the internal streams of the 2^20 pipeline (first exec or plan creation).
-int32_t build_pipeline(fwa_plan *p)
+// W_cur^e = hi[e >> 10] * lo[e & 1023]
+int32_t upload_level(fwa_ctx *ctx, uint64_t cur, v2f **lo, v2f **hi)
+{
+    const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
+    std::vector<v2f> l(nlo), h(nhi);
+    for (uint64_t j = 0; j < nlo; ++j) l[j] = tw_f64(j, cur);
+    for (uint64_t j = 0; j < nhi; ++j) h[j] = tw_f64(1024 * j, cur);
+    int32_t s = upload_table(ctx, l, lo);
+    return s ? s : upload_table(ctx, h, hi);
+}
+
+int32_t build_tables(fwa_ctx *ctx, uint32_t n, int64_t path, const uint32_t lf[3], Tables *t)
+{
+    int32_t st = FWA_OK;
+    if (path == PATH_SMALL) return n >= 2 ? upload_half_table(ctx, n, &t->tw_half) : FWA_OK;
+    if (path == PATH_TWOPASS_1M) {
+        std::vector<v2f> inner(1024);
+        for (uint32_t k1 = 0; k1 < 32; ++k1)
+            for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
+        st = upload_table(ctx, inner, &t->tw_inner);
+        const uint64_t N = 1ull << 20;
+        for (int wi = 0; wi < 2 && !st; ++wi) {
+            const uint32_t W = wi ? 32 : 16, tiles = 1024 / W;
+            std::vector<v2f> outer((size_t)tiles * 64 * W);
+            for (uint32_t tile = 0; tile < tiles; ++tile)
+                for (uint32_t k = 0; k < 32; ++k)
+                    for (uint32_t c = 0; c < W; ++c) {
+                        const uint64_t n2 = (uint64_t)W * tile + c;
+                        outer[(size_t)tile * 64 * W + k * W + c] = tw_f64(n2 * k, N);                // A[k1][c]
+                        outer[(size_t)tile * 64 * W + 32 * W + k * W + c] = tw_f64(32 * n2 * k, N);  // B[k2][c]
+                    }
+            st = upload_table(ctx, outer, &t->tw_outer[wi]);
+        }
+        return st;
+    }
+    if (path == PATH_TILED) {
+        const uint32_t nf = lf[2] ? 3 : 2;
+        for (uint32_t i = 0; i < nf && !st; ++i) st = upload_half_table(ctx, 1u << lf[i], &t->tw_l[i]);
+        if (!st) st = upload_level(ctx, n, &t->tw_lo1, &t->tw_hi1);
+        if (!st && nf == 3) st = upload_level(ctx, (uint64_t)n >> lf[0], &t->tw_lo_b, &t->tw_hi_b);
+        return st;
+    }
+    return FWA_OK;
+}
+
+hipStream_t raw(fwa_stream *s) { return s ? s->s : nullptr; }
+
+struct Pipeline {
+    v2f *ring = nullptr;
+    uint64_t ring_bytes = 0;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork = nullptr;
+};
+
+void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
+{
+    for (auto s : pl.streams) (void)hipStreamDestroy(s);
+    for (auto e : pl.done) (void)hipEventDestroy(e);
+    pl.streams.clear();
+    pl.done.clear();
+    if (pl.fork) { (void)hipEventDestroy(pl.fork); pl.fork = nullptr; }
+    if (pl.ring) {
+        // keep up to 1 GiB of ring allocations of destroyed plans for the next plan of the same shape
+        if (pool_ring && ctx && ctx->free_ring_bytes + pl.ring_bytes <= (1ull << 30)) {
+            ctx->free_rings.emplace(pl.ring_bytes, pl.ring);
+            ctx->free_ring_bytes += pl.ring_bytes;
+        } else {
+            (void)hipFree(pl.ring);
+        }
+        pl.ring = nullptr;
+        pl.ring_bytes = 0;
+    }
+}
+
+Pipeline take_pipeline(fwa_plan *p)
+{
+    Pipeline pl;
+    pl.ring = p->ring; pl.ring_bytes = p->ring_bytes; pl.streams.swap(p->istreams); pl.done.swap(p->idone);
+    pl.fork = p->ev_fork;
+    p->ring = nullptr; p->ring_bytes = 0; p->ev_fork = nullptr;
+    return pl;
+}
+
+// Allocate the scratch ring and the internal streams of the pipelined paths.  The new objects are built first
+// and swapped in only on success, so a failed re-tune (e.g. a group too large for the free memory) leaves the
+// plan exactly as it was.
+int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
 {
     fwa_ctx *ctx = p->ctx;
-    release_pipeline(p);
-    const uint64_t pbatch = p->leaf_batch;
-    if (p->path == PATH_FUSED_1M) {
-        if (pbatch == 0) return FWA_OK;
-        if (p->wgs <= 0) p->wgs = 2 * (int64_t)ctx->prop.multiProcessorCount;
-        if (p->wgs < 64) p->wgs = 64;  // progress guarantee of k_fused_1m needs >= 64 resident workgroups
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->fused_ctl), fwa::fused_ctl_bytes(pbatch)));
+    if (p->path == PATH_RING_1M) {
+        // one launch, no internal streams: ring of min(ring_slots, batch) transforms + the control words
+        Pipeline pl;
+        const uint64_t slots = (uint64_t)p->ring_slots < p->batch ? (uint64_t)p->ring_slots : p->batch;
+        pl.ring_bytes = slots * (sizeof(v2f) << 20);
+        uint32_t *ctl = nullptr;
+        if (pl.ring_bytes) {
+            auto it = ctx->free_rings.find(pl.ring_bytes);
+            if (it != ctx->free_rings.end()) {
+                pl.ring = static_cast<v2f *>(it->second);
+                ctx->free_ring_bytes -= it->first;
+                ctx->free_rings.erase(it);
+                ++ctx->n_ring_reuses;
+            } else {
+                hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
+                if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(ring)");
+                ++ctx->n_ring_allocs;
+            }
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::ring_ctl_bytes(p->batch));
+            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e, "hipMalloc(ring control)"); }
+        }
+        Pipeline old = take_pipeline(p);
+        destroy_pipeline_objects(ctx, old, true);
+        if (p->ring_ctl) (void)hipFree(p->ring_ctl);
+        p->ring_ctl = ctl;
+        p->ring = pl.ring; p->ring_bytes = pl.ring_bytes;
         return FWA_OK;
     }
-    if (p->group < 1) p->group = 1;
-    if ((uint64_t)p->group > pbatch && pbatch) p->group = (int64_t)pbatch;
-    const uint64_t n_groups = pbatch ? (pbatch + p->group - 1) / p->group : 0;
-    if (p->n_streams < 1) p->n_streams = 1;
-    if ((uint64_t)p->n_streams > n_groups && n_groups) p->n_streams = (int64_t)n_groups;
-    p->ring_slots = (uint64_t)p->group * (uint64_t)p->n_streams * ((p->mix && p->path != PATH_TILED) ? 2 : 1);
-    if (p->ring_slots == 0) return FWA_OK;
-    // one slot = one (sub-)transform of the pipeline: 2^20 samples on the two-pass paths, n on the tiled path
-    p->slot_bytes = (p->path == PATH_TILED) ? (uint64_t)p->n * sizeof(v2f) : (sizeof(v2f) << 20);
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->ring), p->ring_slots * p->slot_bytes));
-    if (p->n_streams > 1) {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        for (int64_t i = 0; i < p->n_streams; ++i) {
-            hipStream_t s;
-            hipEvent_t e;
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            p->istreams.push_back(s);
-            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            p->idone.push_back(e);
+    if (p->path != PATH_TWOPASS_1M && p->path != PATH_TILED) return FWA_OK;
+    if (group < 1) group = 1;
+    if ((uint64_t)group > p->batch && p->batch) group = (int64_t)p->batch;
+    const uint64_t n_groups = p->batch ? (p->batch + group - 1) / group : 0;
+    if (n_streams < 1) n_streams = 1;
+    if ((uint64_t)n_streams > n_groups && n_groups) n_streams = (int64_t)n_groups;
+    Pipeline pl;
+    pl.ring_bytes = p->batch ? (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->n * sizeof(v2f) : 0;
+    auto bail = [&](int32_t st) { destroy_pipeline_objects(ctx, pl, false); return st; };
+    if (pl.ring_bytes) {
+        auto it = ctx->free_rings.find(pl.ring_bytes);
+        if (it != ctx->free_rings.end()) {
+            pl.ring = static_cast<v2f *>(it->second);
+            ctx->free_ring_bytes -= it->first;
+            ctx->free_rings.erase(it);
+            ++ctx->n_ring_reuses;
+        } else {
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
+            if (e != hipSuccess) { pl.ring = nullptr; return bail(fail_hip(ctx, e, "hipMalloc(ring)")); }
+            ++ctx->n_ring_allocs;
+        }
+        if (n_streams > 1) {
+            hipError_t e = hipEventCreateWithFlags(&pl.fork, hipEventDisableTiming);
+            if (e != hipSuccess) { pl.fork = nullptr; return bail(fail_hip(ctx, e, "hipEventCreate")); }
+            for (int64_t i = 0; i < n_streams; ++i) {
+                hipStream_t s;
+                hipEvent_t ev;
+                e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+                if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipStreamCreate"));
+                pl.streams.push_back(s);
+                e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipEventCreate"));
+                pl.done.push_back(ev);
+            }
+        }
+    }
+    Pipeline old = take_pipeline(p);
+    destroy_pipeline_objects(ctx, old, true);
+    p->ring = pl.ring; p->ring_bytes = pl.ring_bytes; p->istreams.swap(pl.streams); p->idone.swap(pl.done);
+    p->ev_fork = pl.fork;
+    p->group = group;
+    p->n_streams = n_streams;
+    return FWA_OK;
+}
+
+// tile width of pass i of the tiled path: the plan's cw where the kernel exists for that FFT length
+uint32_t pass_cw(const fwa_plan *p, uint32_t i)
+{
+    return (p->cw == 32 && fwa::tile_supported(p->lf[i], 32)) ? 32u : 16u;
+}
+
+// Everything a plan needs for its path: kernel attributes (once per context), twiddle tables (shared through the
+// context's plan cache) and, on the pipelined paths, the ring + internal streams with the default geometry.
+int32_t setup_path(fwa_plan *p)
+{
+    fwa_ctx *ctx = p->ctx;
+    const uint32_t fft_len = p->n;
+    if (p->path == PATH_SMALL && fft_len > 4096 && !ctx->setup_small_done) {
+        hipError_t e = fwa::setup_small_kernels();
+        if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
+        ctx->setup_small_done = true;
+    }
+    if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M) && !ctx->setup_1m_done) {
+        hipError_t e = fwa::setup_1m_kernels();
+        if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
+        ctx->setup_1m_done = true;
+    }
+    if (p->path == PATH_TILED) {
+        const uint32_t nf = p->lf[2] ? 3 : 2;
+        for (uint32_t i = 0; i < nf; ++i)
+            for (uint32_t cw : {16u, 32u}) {
+                if (!fwa::tile_supported(p->lf[i], cw)) continue;
+                hipError_t pe = fwa::prepare_tile(p->lf[i], cw);
+                if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
+            }
+    }
+    // tables: shared by every plan of this (length, path, factorisation) on the context
+    const uint32_t sig = p->lf[0] | (p->lf[1] << 8) | (p->lf[2] << 16);
+    const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M : p->path, sig);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        p->tb = it->second;
+        ++ctx->n_table_hits;
+    } else {
+        auto tb = std::make_shared<Tables>();
+        int32_t st = build_tables(ctx, fft_len, std::get<1>(key), p->lf, tb.get());
+        if (st) return st;
+        ++ctx->n_table_builds;
+        p->tb = tb;
+        ctx->tables.emplace(key, tb);
+    }
+    if (p->path == PATH_TILED) {
+        // the intermediate of a group of transforms lives in a ring slab of 128 MiB per chain (two chains = the
+        // 256-MiB Infinity Cache; group sweep in profiles/round1/h_tiled_group_sweep.jsonl)
+        const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
+        const int64_t g = (int64_t)((128ull << 20) / per);
+        return build_pipeline(p, g < 1 ? 1 : g, 2);
+    }
+    if (p->path == PATH_TWOPASS_1M) return build_pipeline(p, 16, 2);
+    if (p->path == PATH_RING_1M) return build_pipeline(p, 0, 0);
+    return FWA_OK;
+}
+
+static fwa_buf *result_buffer(fwa_plan *p)
+{
+    // processor.rs:153-157, :335-339, :664-668
+    return (p->lg % 2 == 0) ? p->src : p->second;
+}
+
+// Run `body(group index, stream, chain index)` for every group, alternating over the plan's internal streams,
+// forked from and joined back to the caller's stream with events.
+template <class Body>
+static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
+{
+    fwa_ctx *ctx = plan->ctx;
+    const uint64_t G = (uint64_t)plan->group, n_groups = (plan->batch + G - 1) / G;
+    const size_t ns = plan->istreams.size();
+    if (plan->batch && !plan->ring) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
+    if (ns) {
+        HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
+        for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
+    }
+    hipError_t e = hipSuccess;
+    for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
+        const size_t c = ns ? (size_t)(g % ns) : 0;
+        const uint64_t cnt = (plan->batch - g * G < G) ? plan->batch - g * G : G;
+        e = body(g, cnt, ns ? plan->istreams[c] : st, c);
+    }
+    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
+    if (ns) {
+        for (size_t i = 0; i < ns; ++i) {
+            HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
         }
     }
     return FWA_OK;
@@ -284,7 +525,33 @@ int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out)
 
 int32_t fwa_ctx_destroy(fwa_ctx *ctx)
 {
+    if (!ctx) return FWA_OK;
+    (void)hipSetDevice(ctx->device);
+    for (auto &kv : ctx->free_rings) (void)hipFree(kv.second);
+    ctx->tables.clear();
     delete ctx;
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_synchronize(fwa_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, FWA_ERR_INVALID_ARG, "ctx is NULL");
+    USE_DEVICE(ctx);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
+{
+    if (!ctx || !key || !value) return fail(ctx, FWA_ERR_INVALID_ARG, "NULL argument");
+    const std::string k(key);
+    if (k == "device") *value = ctx->device;
+    else if (k == "table_builds") *value = ctx->n_table_builds;
+    else if (k == "table_cache_hits") *value = ctx->n_table_hits;
+    else if (k == "ring_allocs") *value = ctx->n_ring_allocs;
+    else if (k == "ring_reuses") *value = ctx->n_ring_reuses;
+    else if (k == "last_plan_create_us") *value = ctx->last_plan_create_us;
+    else return fail(ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
     return FWA_OK;
 }
 
@@ -306,7 +573,7 @@ int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
 {
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     hipStream_t s;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     fwa_stream *st = new (std::nothrow) fwa_stream;
@@ -329,6 +596,7 @@ int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out)
 int32_t fwa_stream_synchronize(fwa_stream *stream)
 {
     if (!stream) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    USE_DEVICE(stream->ctx);
     HIP_TRY(stream->ctx, hipStreamSynchronize(stream->s));
     return FWA_OK;
 }
@@ -336,7 +604,7 @@ int32_t fwa_stream_synchronize(fwa_stream *stream)
 int32_t fwa_stream_destroy(fwa_stream *stream)
 {
     if (!stream) return FWA_OK;
-    if (stream->owned) (void)hipStreamDestroy(stream->s);
+    if (stream->owned) { (void)hipSetDevice(stream->ctx->device); (void)hipStreamDestroy(stream->s); }
     delete stream;
     return FWA_OK;
 }
@@ -346,7 +614,7 @@ int32_t fwa_buf_alloc(fwa_ctx *ctx, uint64_t bytes, fwa_buf **out)
 {
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     void *p = nullptr;
     if (bytes) {
         hipError_t e = hipMalloc(&p, bytes);
@@ -374,7 +642,7 @@ int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **o
 int32_t fwa_buf_free(fwa_buf *buf)
 {
     if (!buf) return FWA_OK;
-    if (buf->owned && buf->p) (void)hipFree(buf->p);
+    if (buf->owned && buf->p) { (void)hipSetDevice(buf->ctx->device); (void)hipFree(buf->p); }
     delete buf;
     return FWA_OK;
 }
@@ -385,6 +653,7 @@ int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint
     if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "upload range exceeds buffer");
     if (!bytes) return FWA_OK;
+    USE_DEVICE(dst->ctx);
     HIP_TRY(dst->ctx, hipMemcpyAsync(static_cast<char *>(dst->p) + dst_offset, host, bytes, hipMemcpyHostToDevice,
                                      raw(stream)));
     return FWA_OK;
@@ -396,6 +665,7 @@ int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, ui
     if (src_offset > src->bytes || bytes > src->bytes - src_offset)
         return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
     if (!bytes) return FWA_OK;
+    USE_DEVICE(src->ctx);
     HIP_TRY(src->ctx, hipMemcpyAsync(host, static_cast<const char *>(src->p) + src_offset, bytes,
                                      hipMemcpyDeviceToHost, raw(stream)));
     // map_async + poll(wait) in the reference (examples/basic.rs:105-106): the data is on the host on return
@@ -411,6 +681,7 @@ int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint
         bytes > src->bytes - src_offset)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy range exceeds buffer");
     if (!bytes) return FWA_OK;
+    USE_DEVICE(dst->ctx);
     HIP_TRY(dst->ctx, hipMemcpyAsync(static_cast<char *>(dst->p) + dst_offset,
                                      static_cast<const char *>(src->p) + src_offset, bytes, hipMemcpyDeviceToDevice,
                                      raw(stream)));
@@ -422,7 +693,7 @@ int32_t fwa_host_alloc(fwa_ctx *ctx, uint64_t bytes, void **out)
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
     if (!bytes) return FWA_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
     if (e != hipSuccess) return fail_hip(ctx, e, "hipHostMalloc", FWA_ERR_OUT_OF_MEMORY);
     return FWA_OK;
@@ -441,6 +712,7 @@ int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offs
     if (src_offset > src->bytes || bytes > src->bytes - src_offset)
         return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
     if (!bytes) return FWA_OK;
+    USE_DEVICE(src->ctx);
     HIP_TRY(src->ctx, hipMemcpyAsync(host, static_cast<const char *>(src->p) + src_offset, bytes,
                                      hipMemcpyDeviceToHost, raw(stream)));
     return FWA_OK;
@@ -449,6 +721,7 @@ int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offs
 int32_t fwa_stream_wait_stream(fwa_stream *stream, fwa_stream *other)
 {
     if (!stream || !other) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    USE_DEVICE(stream->ctx);
     hipEvent_t ev;
     HIP_TRY(stream->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t e = hipEventRecord(ev, other->s);
@@ -465,13 +738,14 @@ uint64_t fwa_buf_size(const fwa_buf *buf) { return buf ? buf->bytes : 0; }
 int32_t fwa_plan_destroy(fwa_plan *plan)
 {
     if (!plan) return FWA_OK;
-    release_pipeline(plan);
-    if (plan->tw_half) (void)hipFree(plan->tw_half);
-    if (plan->tw_inner) (void)hipFree(plan->tw_inner);
-    if (plan->tw_outer) (void)hipFree(plan->tw_outer);
-    for (v2f *t : {plan->tw_lo1, plan->tw_hi1, plan->tw_lo2, plan->tw_hi2, plan->tw_l[0], plan->tw_l[1], plan->tw_l[2],
-                   plan->tw_lo_b, plan->tw_hi_b})
-        if (t) (void)hipFree(t);
+    (void)hipSetDevice(plan->ctx->device);
+    // work of this plan may still be in flight on the caller's stream; the pooled ring must not be handed to the
+    // next plan before it has drained (hipFree would have synchronised implicitly)
+    if (plan->frozen && plan->ring) (void)hipDeviceSynchronize();
+    Pipeline pl = take_pipeline(plan);
+    destroy_pipeline_objects(plan->ctx, pl, true);
+    if (plan->ring_ctl) (void)hipFree(plan->ring_ctl);
+    if (plan->tw_half_private) (void)hipFree(plan->tw_half_private);
     if (plan->second_owned && plan->own_second.p) (void)hipFree(plan->own_second.p);
     delete plan;
     return FWA_OK;
@@ -500,7 +774,8 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return fail(ctx, FWA_ERR_INVALID_ARG, "the two buffers must be distinct");
     if (reinterpret_cast<uintptr_t>(src->p) & 15) return fail(ctx, FWA_ERR_INVALID_ARG, "buffer must be 16-byte aligned");
 
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    USE_DEVICE(ctx);
     fwa_plan *p = new (std::nothrow) fwa_plan;
     if (!p) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
     p->ctx = ctx; p->kind = kind; p->n = fft_len; p->lg = ilog2(fft_len);
@@ -509,28 +784,24 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
 
     int32_t st = FWA_OK;
     auto bail = [&](int32_t s) { fwa_plan_destroy(p); return s; };
+    auto done = [&]() {
+        ctx->last_plan_create_us =
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
+        *out = p;
+        return FWA_OK;
+    };
 
     if (kind == FWA_NORMALIZE) {
         p->path = PATH_NORMALIZE;
-        *out = p;
-        return FWA_OK;
+        return done();
     }
 
-    p->path = choose_path(fft_len, p->lf);  // PATH_FUSED_1M is opt-in (experimental)
-    if (p->path == PATH_TILED && std::getenv("FWA_FORCE_SPLIT")) p->path = PATH_SPLIT;  // cross-check path
-    p->leaf_batch = p->batch;
-    if (p->path == PATH_SPLIT) {
-        p->leaf = (fft_len > (1u << 20)) ? (1u << 20) : 4096u;
-        const uint32_t rt = fft_len / p->leaf;
-        p->r1 = rt <= 32 ? rt : 32;
-        p->r2 = rt / p->r1;
-        p->leaf_batch = p->batch * rt;
-    }
+    p->path = choose_path(fft_len, p->batch, p->lf);
 
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
     // materialised when the result must land there (odd log2 n) or the path ping-pongs.
     const bool odd = (p->lg & 1) != 0;
-    const bool need_second = odd || p->path == PATH_R2_GLOBAL || p->path == PATH_SPLIT;
+    const bool need_second = odd || p->path == PATH_R2_GLOBAL;
     if (!p->second && need_second && src->bytes) {
         hipError_t e = hipMalloc(&p->own_second.p, src->bytes);
         if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipMalloc(second buffer)"));
@@ -544,153 +815,16 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         p->second = &p->own_second;
     }
 
-    if (p->path == PATH_LDS_SMALL && fft_len > 4096 && !ctx->setup_small_done) {
-        hipError_t e = fwa::setup_small_kernels();
-        if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
-        ctx->setup_small_done = true;
-    }
-    auto level = [&](uint64_t cur, v2f **lo, v2f **hi) -> int32_t {
-        const uint64_t nlo = cur < 1024 ? cur : 1024, nhi = cur < 1024 ? 1 : cur / 1024;
-        std::vector<v2f> l(nlo), h(nhi);
-        for (uint64_t j = 0; j < nlo; ++j) l[j] = tw_f64(j, cur);
-        for (uint64_t j = 0; j < nhi; ++j) h[j] = tw_f64(1024 * j, cur);
-        int32_t s = upload_table(ctx, l, lo);
-        return s ? s : upload_table(ctx, h, hi);
-    };
-    if (p->path == PATH_TILED) {
-        const uint32_t nf = p->lf[2] ? 3 : 2;
-        for (uint32_t i = 0; i < nf; ++i) {
-            const uint32_t L = 1u << p->lf[i];
-            std::vector<v2f> h(L / 2);
-            for (uint32_t k = 0; k < L / 2; ++k) h[k] = tw_f64(k, L);
-            st = upload_table(ctx, h, &p->tw_l[i]);
-            if (st) return bail(st);
-            hipError_t pe = fwa::prepare_tile16(p->lf[i]);
-            if (pe != hipSuccess) return bail(fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)"));
-        }
-        st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
-        if (st) return bail(st);
-        if (nf == 3) {
-            st = level((uint64_t)fft_len >> p->lf[0], &p->tw_lo_b, &p->tw_hi_b);
-            if (st) return bail(st);
-        }
-        // intermediate of a group of transforms lives in a ring slab of 128 MiB per chain (two chains = the
-        // 256-MiB Infinity Cache; group sweep in profiles/round1/h_tiled_group_sweep.jsonl)
-        const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
-        p->group = (int64_t)((128ull << 20) / per);
-        if (p->group < 1) p->group = 1;
-        st = build_pipeline(p);
-        if (st) return bail(st);
-    }
-    if (p->path == PATH_SPLIT) {
-        st = level(fft_len, &p->tw_lo1, &p->tw_hi1);
-        if (st) return bail(st);
-        if (p->r2 > 1) {
-            st = level(fft_len / p->r1, &p->tw_lo2, &p->tw_hi2);
-            if (st) return bail(st);
-        }
-    }
-    const uint32_t leaf_n = (p->path == PATH_SPLIT) ? p->leaf : fft_len;
-    if (p->path == PATH_LDS_SMALL || p->path == PATH_R2_GLOBAL || (p->path == PATH_SPLIT && leaf_n == 4096)) {
-        std::vector<v2f> h(leaf_n / 2);
-        for (uint32_t k = 0; k < leaf_n / 2; ++k) h[k] = tw_f64(k, leaf_n);
-        st = upload_table(ctx, h, &p->tw_half);
-        if (st) return bail(st);
-    } else if (p->path == PATH_TWOPASS_1M || p->path == PATH_FUSED_1M || p->path == PATH_SPLIT) {
-        if (!ctx->setup_1m_done) {
-            hipError_t e = fwa::setup_1m_kernels();
-            if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)"));
-            ctx->setup_1m_done = true;
-        }
-        std::vector<v2f> inner(1024), outer((size_t)64 * 1024);
-        for (uint32_t k1 = 0; k1 < 32; ++k1)
-            for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
-        const uint64_t N = 1ull << 20;
-        for (uint32_t tile = 0; tile < 64; ++tile)
-            for (uint32_t k = 0; k < 32; ++k)
-                for (uint32_t c = 0; c < 16; ++c) {
-                    const uint64_t n2 = 16 * tile + c;
-                    outer[(size_t)tile * 1024 + k * 16 + c] = tw_f64(n2 * k, N);             // A[k1][c]
-                    outer[(size_t)tile * 1024 + 512 + k * 16 + c] = tw_f64(32 * n2 * k, N);  // B[k2][c]
-                }
-        st = upload_table(ctx, inner, &p->tw_inner);
-        if (st) return bail(st);
-        st = upload_table(ctx, outer, &p->tw_outer);
-        if (st) return bail(st);
-        st = build_pipeline(p);
-        if (st) return bail(st);
-    }
-    *out = p;
-    return FWA_OK;
-}
-
-static fwa_buf *result_buffer(fwa_plan *p)
-{
-    // processor.rs:153-157, :335-339, :664-668
-    return (p->lg % 2 == 0) ? p->src : p->second;
-}
-
-// The 2^20 two-pass pipeline on `nb` transforms starting at `a` (results to `out`, may alias `a`).
-static int32_t exec_twopass(fwa_plan *plan, int dir, v2f *a, v2f *out, uint64_t nb, float scale, hipStream_t st)
-{
-    fwa_ctx *ctx = plan->ctx;
-    hipError_t e = hipSuccess;
-    const uint64_t G = (uint64_t)plan->group;
-    const uint64_t n_groups = (nb + G - 1) / G;
-    const size_t ns = plan->istreams.size();
-    const size_t chains = ns ? ns : 1;
-    const uint64_t N = 1ull << 20;
-    if (ns) {
-        HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
-        for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
-    }
-    auto count = [&](uint64_t g) { return (uint32_t)((nb - g * G < G) ? nb - g * G : G); };
-    if (plan->mix) {
-        // chain c owns groups c, c+chains, ...; launch i of a chain = pass 1 of its i-th group next to
-        // pass 2 of its (i-1)-th group; two ring slabs per chain, used alternately.
-        const uint64_t rounds = (n_groups + chains - 1) / chains;
-        for (uint64_t i = 0; i <= rounds && e == hipSuccess; ++i) {
-            for (size_t c = 0; c < chains && e == hipSuccess; ++c) {
-                const uint64_t g = i * chains + c, gp = g - chains;  // gp valid when i > 0
-                const bool has1 = (i < rounds) && g < n_groups;
-                const bool has2 = (i > 0) && gp < n_groups;
-                if (!has1 && !has2) continue;
-                v2f *slab_w = plan->ring + ((uint64_t)c * 2 + (i & 1)) * G * N;
-                v2f *slab_r = plan->ring + ((uint64_t)c * 2 + ((i + 1) & 1)) * G * N;
-                e = fwa::launch_mix_1m(dir, (int)plan->policy, has1 ? a + g * G * N : a, slab_w, has1 ? count(g) : 0,
-                                       slab_r, has2 ? out + gp * G * N : out, has2 ? count(gp) : 0, plan->tw_inner,
-                                       plan->tw_outer, scale, (uint32_t)plan->dbg, ns ? plan->istreams[c] : st);
-            }
-        }
-    } else {
-        for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
-            const uint64_t t0 = g * G;
-            const uint32_t cnt = count(g);
-            const size_t si = ns ? (size_t)(g % ns) : 0;
-            hipStream_t s = ns ? plan->istreams[si] : st;
-            // ring region of this stream: G slots; inside a group transform t uses slot (t - t0)
-            v2f *ring = plan->ring + (uint64_t)si * G * N;
-            e = fwa::launch_p1_1m(dir, (int)plan->policy, a + t0 * N, ring, plan->tw_inner, plan->tw_outer, (uint32_t)G,
-                                  0, cnt, s);
-            if (e != hipSuccess) break;
-            e = fwa::launch_p2_1m(dir, (int)plan->policy, ring, out + t0 * N, plan->tw_inner, (uint32_t)G, 0, cnt, scale,
-                                  s);
-        }
-    }
-    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
-    if (ns) {
-        for (size_t i = 0; i < ns; ++i) {
-            HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
-        }
-    }
-    return FWA_OK;
+    st = setup_path(p);
+    if (st) return bail(st);
+    return done();
 }
 
 int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
 {
     if (!plan) return fail(nullptr, FWA_ERR_INVALID_ARG, "plan is NULL");
     fwa_ctx *ctx = plan->ctx;
+    USE_DEVICE(ctx);
     hipStream_t st = raw(stream);
     plan->frozen = true;
     const uint64_t total = plan->batch * (uint64_t)plan->n;
@@ -715,35 +849,50 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
     v2f *a = static_cast<v2f *>(plan->src->p);
     v2f *b = static_cast<v2f *>(plan->second->p);
     v2f *out = static_cast<v2f *>(res->p);
+    const Tables &tb = *plan->tb;
+    const uint64_t N = plan->n, G = (uint64_t)plan->group;
 
     switch (plan->path) {
         case PATH_IDENTITY:
             if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
             break;
-        case PATH_LDS_SMALL:
+        case PATH_SMALL:
             if (plan->small_reg && plan->n < 16)
                 e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
             else if (plan->small_reg)
-                e = fwa::launch_small16(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
+                e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
             else
-                e = fwa::launch_lds_small(dir, a, out, plan->tw_half, plan->n, plan->batch, scale, st);
+                e = fwa::launch_lds_small(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
             break;
-        case PATH_R2_GLOBAL:
+        case PATH_R2_GLOBAL: {
+            const v2f *tw = plan->tw_half_private ? plan->tw_half_private : tb.tw_half;
             for (uint32_t s = 0; s < plan->lg && e == hipSuccess; ++s) {
                 const v2f *from = (s % 2 == 0) ? a : b;
                 v2f *to = (s % 2 == 0) ? b : a;
-                e = fwa::launch_r2_stage(dir, from, to, plan->tw_half, plan->n, s, plan->batch,
-                                         (s + 1 == plan->lg) ? scale : 1.0f, st);
+                e = fwa::launch_r2_stage(dir, from, to, tw, plan->n, s, plan->batch, (s + 1 == plan->lg) ? scale : 1.0f,
+                                         st);
             }
             break;
-        case PATH_FUSED_1M:
-            // in place: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
-            e = fwa::launch_fused_1m(dir, (int)plan->policy, a, plan->tw_inner, plan->tw_outer, plan->fused_ctl, (uint32_t)plan->batch,
-                                     (uint32_t)plan->depth, (uint32_t)plan->wgs, scale, (uint32_t)plan->dbg, st);
-            break;
+        }
         case PATH_TWOPASS_1M: {
-            const int32_t s2 = exec_twopass(plan, dir, a, out, plan->batch, scale, st);
-            if (s2) return s2;
+            // in place at group granularity: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
+            const int w = (int)plan->tile_w;
+            const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
+            return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
+                v2f *slab = plan->ring + (uint64_t)c * G * N;  // ring region of this chain: transform i -> slot i
+                hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt,
+                                                  (uint32_t)plan->xcd_swizzle, s);
+                if (le != hipSuccess) return le;
+                return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale,
+                                         (uint32_t)plan->xcd_swizzle, s);
+            });
+        }
+        case PATH_RING_1M: {
+            if (!plan->ring || !plan->ring_ctl) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
+            const uint64_t slots = (uint64_t)plan->ring_slots < plan->batch ? (uint64_t)plan->ring_slots : plan->batch;
+            const uint64_t depth = (uint64_t)plan->depth < slots ? (uint64_t)plan->depth : (slots > 1 ? slots - 1 : 1);
+            e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer[0], plan->ring_ctl, (uint32_t)plan->batch,
+                                    (uint32_t)depth, (uint32_t)(slots > depth ? slots : depth + 1), (uint32_t)plan->wgs, scale, st);
             break;
         }
         case PATH_TILED: {
@@ -752,80 +901,41 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             // twiddle W_{N2*N3}), in place in the slab]; pass C: FFT over the contiguous axis with the transposed
             // store, slab -> result buffer (src for even log2 n -- in place at group granularity -- else second).
             const bool three = plan->lf[2] != 0;
-            const uint64_t N = plan->n, N1 = 1ull << plan->lf[0], N2 = 1ull << plan->lf[1],
-                           N3 = three ? (1ull << plan->lf[2]) : 1;
-            const uint64_t G = (uint64_t)plan->group, n_groups = (plan->batch + G - 1) / G;
-            const size_t ns = plan->istreams.size();
-            if (ns) {
-                HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
-                for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
-            }
-            for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
-                const uint64_t cnt = (plan->batch - g * G < G) ? plan->batch - g * G : G;
-                const size_t c = ns ? (size_t)(g % ns) : 0;
-                hipStream_t s = ns ? plan->istreams[c] : st;
+            const uint64_t N1 = 1ull << plan->lf[0], N2 = 1ull << plan->lf[1], N3 = three ? (1ull << plan->lf[2]) : 1;
+            return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 v2f *slab = plan->ring + (uint64_t)c * G * N;
                 fwa::TileArgs ta{};
-                ta.scale = 1.0f;
-                ta.flags = (uint32_t)plan->dbg;
+                ta.xcd_swizzle = (uint32_t)plan->xcd_swizzle;
                 // pass A
-                ta.in = a + g * G * N; ta.out = slab; ta.tw = plan->tw_l[0]; ta.tw_lo = plan->tw_lo1; ta.tw_hi = plan->tw_hi1;
-                ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = 16;
-                ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / 16);
-                ta.flags = (uint32_t)plan->dbg | (plan->policy ? (1u << 8) : 0);  // first pass: user buffer -> ring
-                e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
-                if (e != hipSuccess) break;
+                uint32_t cw = pass_cw(plan, 0);
+                ta.in = a + g * G * N; ta.out = slab; ta.tw = tb.tw_l[0]; ta.tw_lo = tb.tw_lo1; ta.tw_hi = tb.tw_hi1;
+                ta.scale = 1.0f; ta.cw = cw; ta.role = fwa::ROLE_FIRST;
+                ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
+                ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
+                hipError_t le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
+                if (le != hipSuccess) return le;
                 if (three) {  // pass B, in place in the slab
-                    ta.in = slab; ta.out = slab; ta.tw = plan->tw_l[1]; ta.tw_lo = plan->tw_lo_b; ta.tw_hi = plan->tw_hi_b;
+                    cw = pass_cw(plan, 1);
+                    if (N3 < cw) cw = 16;
+                    ta.in = slab; ta.out = slab; ta.tw = tb.tw_l[1]; ta.tw_lo = tb.tw_lo_b; ta.tw_hi = tb.tw_hi_b;
+                    ta.cw = cw; ta.role = fwa::ROLE_MIDDLE; ta.in_st = ta.out_st = cw;
                     ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1;
-                    ta.tile_count = (uint32_t)(N3 / 16);
-                    ta.flags = (uint32_t)plan->dbg | (plan->policy ? (2u << 8) : 0);  // middle pass: ring -> ring
-                    e = fwa::launch_tile16(dir, fwa::TILE_COLS, plan->lf[1], ta, cnt, s);
-                    if (e != hipSuccess) break;
+                    ta.tile_count = (uint32_t)(N3 / cw);
+                    le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[1], ta, cnt, s);
+                    if (le != hipSuccess) return le;
                 }
-                // pass C: rows of the last axis, 16 adjacent k1 per tile
+                // pass C: rows of the last axis, cw adjacent k1 per tile
                 const uint32_t li = three ? 2 : 1;
-                ta.in = slab; ta.out = out + g * G * N; ta.tw = plan->tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
-                ta.scale = scale;
+                cw = pass_cw(plan, li);
+                ta.in = slab; ta.out = out + g * G * N; ta.tw = tb.tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
+                ta.scale = scale; ta.cw = cw; ta.role = fwa::ROLE_LAST;
                 ta.in_sb = ta.out_sb = N;
                 ta.pitch = N / N1;  // distance between the rows k1 and k1+1
-                ta.in_st = 16 * (N / N1); ta.out_st = 16; ta.tile_count = (uint32_t)(N1 / 16);
+                ta.in_st = cw * (N / N1); ta.out_st = cw; ta.tile_count = (uint32_t)(N1 / cw);
                 if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
                 else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
-                ta.flags = (uint32_t)plan->dbg | (plan->policy ? (3u << 8) : 0);  // last pass: ring -> user buffer
-                e = fwa::launch_tile16(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, cnt, s);
-            }
-            if (e != hipSuccess) break;
-            if (ns) {
-                for (size_t i = 0; i < ns; ++i) {
-                    HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
-                    HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
-                }
-            }
-            break;
-        }
-        case PATH_SPLIT: {
-            // even log2 n: src -> second (pass 1), work in second, permute back into src; odd: work in src,
-            // permute into second -- the result lands where processor.rs:153-157 says.
-            const uint32_t lg_m = ilog2(plan->leaf), lg_r1 = ilog2(plan->r1), lg_r2 = ilog2(plan->r2);
-            v2f *work = (plan->lg % 2 == 0) ? b : a;
-            e = fwa::launch_radix_pass(dir, (int)plan->r1, a, work, plan->tw_lo1, plan->tw_hi1, lg_m + lg_r2,
-                                       plan->batch, st);
-            if (e == hipSuccess && plan->r2 > 1)
-                e = fwa::launch_radix_pass(dir, (int)plan->r2, work, work, plan->tw_lo2, plan->tw_hi2, lg_m,
-                                           plan->batch * plan->r1, st);
-            if (e != hipSuccess) break;
-            if (plan->leaf == (1u << 20)) {
-                const int32_t s2 = exec_twopass(plan, dir, work, work, plan->leaf_batch, 1.0f, st);
-                if (s2) return s2;
-            } else {
-                e = plan->small_reg
-                        ? fwa::launch_small16(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, false, st)
-                        : fwa::launch_lds_small(dir, work, work, plan->tw_half, plan->leaf, plan->leaf_batch, 1.0f, st);
-                if (e != hipSuccess) break;
-            }
-            e = fwa::launch_permute(work, out, lg_r1, lg_r2, lg_m, plan->batch, scale, st);
-            break;
+                return fwa::launch_tile(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, cnt, s);
+            });
         }
         default:
             return fail(ctx, FWA_ERR_UNSUPPORTED, "plan path not implemented");
@@ -839,7 +949,7 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
     if (!path || !log2_factors) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
     if (!is_pow2(fft_len)) return fail(nullptr, FWA_ERR_INVALID_ARG, "fft_len must be a power of two >= 1");
     if (fft_len > (1u << 30)) return fail(nullptr, FWA_ERR_UNSUPPORTED, "fft_len above 2^30 is not supported");
-    *path = (int32_t)choose_path(fft_len, log2_factors);
+    *path = (int32_t)choose_path(fft_len, ~0ull, log2_factors);
     return FWA_OK;
 }
 
@@ -847,52 +957,39 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
 {
     if (!plan || !key || !value) return fail(plan ? plan->ctx : nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
     const std::string k(key);
+    const int64_t ng = plan->group ? (int64_t)((plan->batch + plan->group - 1) / plan->group) : 0;
     if (k == "batch") *value = (int64_t)plan->batch;
     else if (k == "fft_len") *value = plan->n;
     else if (k == "path") *value = plan->path;
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
+    else if (k == "tile_w") *value = plan->tile_w;
+    else if (k == "cw") *value = plan->cw;
+    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle;
     else if (k == "depth") *value = plan->depth;
+    else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;
-    else if (k == "policy") *value = plan->policy;
-    else if (k == "mix") *value = plan->mix;
-    else if (k == "small_reg") *value = plan->small_reg;
     else if (k == "device_error") {
-        // bounded-spin timeout flag of the fused kernel (0 in every healthy run); synchronises the device
+        // bounded-spin timeout flag of the persistent kernel (0 in every healthy run); synchronises the device
         *value = 0;
-        if (plan->fused_ctl) {
+        if (plan->ring_ctl) {
             uint32_t w = 0;
             HIP_TRY(plan->ctx, hipDeviceSynchronize());
-            HIP_TRY(plan->ctx, hipMemcpy(&w, plan->fused_ctl + 1, sizeof(w), hipMemcpyDeviceToHost));
+            HIP_TRY(plan->ctx, hipMemcpy(&w, plan->ring_ctl + 1, sizeof(w), hipMemcpyDeviceToHost));
             *value = w;
         }
     }
+    else if (k == "small_reg") *value = plan->small_reg;
+    else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
+    else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
-        *value = (int64_t)(plan->ring_slots * plan->slot_bytes) +
-                 (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
-                 (plan->fused_ctl ? (int64_t)fwa::fused_ctl_bytes(plan->batch) : 0);
+        *value = (int64_t)plan->ring_bytes + (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
+                 (plan->ring_ctl ? (int64_t)fwa::ring_ctl_bytes(plan->batch) : 0);
     else if (k == "launches_per_exec") {
         switch (plan->path) {
-            case PATH_TWOPASS_1M: {
-                const int64_t ng = (int64_t)((plan->batch + plan->group - 1) / plan->group);
-                const int64_t ch = plan->istreams.empty() ? 1 : (int64_t)plan->istreams.size();
-                *value = plan->mix ? ng + (ng < ch ? ng : ch) : 2 * ng;
-                break;
-            }
-            case PATH_FUSED_1M: *value = 1; break;
-            case PATH_TILED:
-                *value = (plan->lf[2] ? 3 : 2) * (int64_t)((plan->batch + plan->group - 1) / plan->group);
-                break;
-            case PATH_SPLIT: {
-                int64_t leafl = 1;
-                if (plan->leaf == (1u << 20)) {
-                    const int64_t ng = (int64_t)((plan->leaf_batch + plan->group - 1) / plan->group);
-                    const int64_t ch = plan->istreams.empty() ? 1 : (int64_t)plan->istreams.size();
-                    leafl = plan->mix ? ng + (ng < ch ? ng : ch) : 2 * ng;
-                }
-                *value = 1 + (plan->r2 > 1 ? 1 : 0) + leafl + 1;
-                break;
-            }
+            case PATH_TWOPASS_1M: *value = 2 * ng; break;
+            case PATH_RING_1M: *value = 1; break;
+            case PATH_TILED: *value = (plan->lf[2] ? 3 : 2) * ng; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
             default: *value = 1;
@@ -905,68 +1002,103 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
 {
     if (!plan || !key) return fail(plan ? plan->ctx : nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
     if (plan->frozen) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "plan tunables are locked after the first exec");
+    fwa_ctx *ctx = plan->ctx;
+    USE_DEVICE(ctx);
     const std::string k(key);
     if (k == "group" || k == "streams") {
-        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED && !(plan->path == PATH_SPLIT && plan->leaf == (1u << 20)))
-            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 pipeline");
-        if (value < 1 || value > 4096) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
-        if (k == "group") plan->group = value; else plan->n_streams = value;
-        return build_pipeline(plan);
+        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths (2^20 two-pass, tiled)");
+        if (value < 1 || value > 4096) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        return build_pipeline(plan, k == "group" ? value : plan->group, k == "streams" ? value : plan->n_streams);
     }
-    if (k == "dbg") { plan->dbg = value; return FWA_OK; }
+    if (k == "tile_w") {
+        if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
+        if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "tile_w is 16 or 32");
+        plan->tile_w = value;
+        return FWA_OK;
+    }
+    if (k == "depth" || k == "ring_slots" || k == "wgs") {
+        if (plan->path != PATH_RING_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
+        if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (k == "wgs") { plan->wgs = value; return FWA_OK; }
+        const int64_t d = k == "depth" ? value : plan->depth, r = k == "ring_slots" ? value : plan->ring_slots;
+        if (k == "depth") { plan->depth = d; if (r < d + 1) plan->ring_slots = d + 1; }
+        else { if (r < plan->depth + 1) return fail(ctx, FWA_ERR_INVALID_ARG, "ring_slots must exceed depth"); plan->ring_slots = r; }
+        return build_pipeline(plan, 0, 0);
+    }
+    if (k == "xcd_swizzle") {
+        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths");
+        plan->xcd_swizzle = value & 3;
+        return FWA_OK;
+    }
+    if (k == "cw") {
+        if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the tiled path");
+        if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "cw is 16 or 32");
+        plan->cw = value;
+        return FWA_OK;
+    }
+    if (k == "factors") {
+        // re-factorise a multi-pass plan: value = log2(N1) | log2(N2) << 8 | log2(N3) << 16 (N3 = 0: two passes), every
+        // factor 64..1024, product n.  A tuning knob: every factorisation computes the same transform.
+        if (plan->path != PATH_TILED && plan->path != PATH_TWOPASS_1M)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to multi-pass plans");
+        const uint32_t f[3] = {(uint32_t)value & 255u, (uint32_t)(value >> 8) & 255u, (uint32_t)(value >> 16) & 255u};
+        const uint32_t nf = f[2] ? 3 : 2;
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < nf; ++i) {
+            if (f[i] < 6 || f[i] > 10) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10");
+            sum += f[i];
+        }
+        if (sum != plan->lg || (value >> 24)) return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");
+        const int64_t old_path = plan->path;
+        uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
+        plan->path = PATH_TILED;
+        plan->lf[0] = f[0]; plan->lf[1] = f[1]; plan->lf[2] = f[2];
+        const int32_t st = setup_path(plan);
+        if (st) { plan->path = old_path; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
+        return st;
+    }
     if (k == "small_reg") {
-        if (!value && plan->n > 4096) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
+        if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 16384");
+        if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
         plan->small_reg = value == 2 ? 2 : (value ? 1 : 0);  // 2: wavefront-shuffle exchange at n = 32/64/128
         return FWA_OK;
     }
-    if (k == "mix") {
-        if (plan->path != PATH_TWOPASS_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the two-launch 2^20 path");
-        plan->mix = value ? 1 : 0;
-        return build_pipeline(plan);
-    }
-    if (k == "policy") {
-        if (value < 0 || value > 7) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "policy out of range");
-        plan->policy = value;
-        return FWA_OK;
-    }
-    if (k == "depth" || k == "wgs") {
-        if (plan->path != PATH_FUSED_1M) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "key only applies to the fused 2^20 path");
-        if (value < 1 || value > 65536) return fail(plan->ctx, FWA_ERR_INVALID_ARG, "value out of range");
-        if (k == "depth") plan->depth = value; else plan->wgs = value < 64 ? 64 : value;
-        return FWA_OK;
-    }
     if (k == "path") {
-        if (plan->kind == FWA_NORMALIZE) return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
-        if (value == PATH_FUSED_1M && plan->batch >= (1u << 24))
-            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "fused path needs batch < 2^24");
-        if ((value == PATH_TWOPASS_1M || value == PATH_FUSED_1M) && plan->n == (1u << 20)) {
+        if (plan->kind == FWA_NORMALIZE) return fail(ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
+        if (value == plan->path) return FWA_OK;
+        if ((value == PATH_RING_1M || value == PATH_TWOPASS_1M) && (plan->path == PATH_RING_1M || plan->path == PATH_TWOPASS_1M)) {
+            // the two forms of the 2^20 pipeline: per-group launches with a large ring, or one persistent launch
+            const int64_t old = plan->path;
             plan->path = value;
-            return build_pipeline(plan);
+            const int32_t st = setup_path(plan);
+            if (st) plan->path = old;
+            if (!st && value == PATH_TWOPASS_1M && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
+            return st;
         }
-        if (value == PATH_TILED || value == PATH_SPLIT)
-            return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "tiled/split are chosen at plan creation (FWA_FORCE_SPLIT=1 selects split)");
         if (value == PATH_R2_GLOBAL && plan->n >= 2) {
-            // force the literal reference recurrence (one launch per stage)
-            if (!plan->tw_half) {
-                std::vector<v2f> h(plan->n / 2);
-                for (uint32_t i = 0; i < plan->n / 2; ++i) h[i] = tw_f64(i, plan->n);
-                int32_t st = upload_table(plan->ctx, h, &plan->tw_half);
+            // force the literal reference recurrence (one launch per stage, kernel/fft.wgsl:27-62)
+            if (!plan->tb->tw_half && !plan->tw_half_private) {
+                int32_t st = upload_half_table(ctx, plan->n, &plan->tw_half_private);
                 if (st) return st;
             }
             if (!plan->second->p && plan->src->bytes) {
-                if (plan->second != &plan->own_second)
-                    return fail(plan->ctx, FWA_ERR_INVALID_ARG, "second buffer missing");
+                if (plan->second != &plan->own_second) return fail(ctx, FWA_ERR_INVALID_ARG, "second buffer missing");
                 hipError_t e = hipMalloc(&plan->own_second.p, plan->src->bytes);
-                if (e != hipSuccess) return fail_hip(plan->ctx, e, "hipMalloc(second buffer)");
+                if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(second buffer)");
                 plan->own_second.bytes = plan->src->bytes;
                 plan->second_owned = true;
             }
+            Pipeline pl = take_pipeline(plan);
+            destroy_pipeline_objects(ctx, pl, true);
+            if (plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
             plan->path = PATH_R2_GLOBAL;
             return FWA_OK;
         }
-        return fail(plan->ctx, FWA_ERR_UNSUPPORTED, "only path=2 (radix-2 global) or, at n=2^20, 1/5 can be forced");
+        return fail(ctx, FWA_ERR_UNSUPPORTED, "only path = 2 (the literal radix-2 recurrence) or, at n = 2^20, 1 / 5 can be set");
     }
-    return fail(plan->ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
+    return fail(ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
 }
 
 // ---- events ----------------------------------------------------------------
@@ -974,6 +1106,7 @@ int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out)
 {
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
+    USE_DEVICE(ctx);
     hipEvent_t e;
     HIP_TRY(ctx, hipEventCreate(&e));
     fwa_event *ev = new (std::nothrow) fwa_event;
@@ -985,12 +1118,14 @@ int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out)
 int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream)
 {
     if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    USE_DEVICE(ev->ctx);
     HIP_TRY(ev->ctx, hipEventRecord(ev->e, raw(stream)));
     return FWA_OK;
 }
 int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms)
 {
     if (!start || !end || !ms) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    USE_DEVICE(end->ctx);
     HIP_TRY(end->ctx, hipEventSynchronize(end->e));
     HIP_TRY(end->ctx, hipEventElapsedTime(ms, start->e, end->e));
     return FWA_OK;
@@ -1008,6 +1143,7 @@ int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform
                            fwa_stream *stream)
 {
     if (!dst || !fft_len) return fail(dst ? dst->ctx : nullptr, FWA_ERR_INVALID_ARG, "dst NULL or fft_len 0");
+    USE_DEVICE(dst->ctx);
     hipError_t e = fwa::launch_fill(static_cast<v2f *>(dst->p), seed, first_transform * (uint64_t)fft_len,
                                     dst->bytes / 8, scale, raw(stream));
     if (e != hipSuccess) return fail_hip(dst->ctx, e, "fill launch", FWA_ERR_LAUNCH);
@@ -1019,6 +1155,7 @@ int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_str
     if (!dst || !src) return fail(nullptr, FWA_ERR_INVALID_ARG, "dst/src is NULL");
     if (bytes > dst->bytes || bytes > src->bytes || (bytes & 15))
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
+    USE_DEVICE(dst->ctx);
     hipError_t e = fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
     if (e != hipSuccess) return fail_hip(dst->ctx, e, "copy launch", FWA_ERR_LAUNCH);
     return FWA_OK;

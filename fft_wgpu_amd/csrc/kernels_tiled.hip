@@ -1,44 +1,59 @@
-// kernels_tiled.hip -- (2/3) multi-pass building blocks: k_tile16, strided radix passes, permute.
+// kernels_tiled.hip -- (2/3) the building block of the 2- and 3-pass paths: k_tile.
 #include "device_common.h"
 
 namespace fwa {
 
 // ---------------------------------------------------------------------------
-// k_tile16: 16 FFTs of length L (64 <= L <= 1024) per workgroup along ONE axis of a multi-dimensional view
-// of the transform -- the building block of the 2- and 3-pass paths for n = 2^15..2^19 and 2^21..2^30
-// (n = N1*N2[*N3]).  Same register radix-16 Stockham stages as k_small16; what differs is addressing:
-//   COLS  (strided axis): element i of FFT c at in + i*pitch + c; 16 adjacent c = one 128-B segment, so
+// k_tile: CW FFTs of length L (64 <= L <= 1024) per workgroup along ONE axis of a multi-dimensional view
+// of the transform -- the building block of the 2- and 3-pass paths (n = N1*N2[*N3]).  Same register radix-16
+// Stockham stages as k_small16; what differs is addressing:
+//   COLS  (strided axis): element i of FFT c at in + i*pitch + c; CW adjacent c = one CW*8-byte segment, so
 //         loads and stores are coalesced over c.  Output element o is multiplied by the four-step twiddle
 //         W_T^{(col0 + c)*o} = hi[e>>10]*lo[e&1023] and stored at out + o*pitch + c (in place allowed).
 //   ROWS_T (last axis): FFT c is a contiguous row at in + c*row_pitch; loads are coalesced along the row,
 //         the exchange re-maps threads, and output element o of row c goes to out + o*out_stride + c
-//         (16 adjacent rows = one 128-B segment): the transposed store that restores natural order.
+//         (CW adjacent rows = one segment): the transposed store that restores natural order.
+// LDS: one padded array per FFT (pad(p) = p + p/16, conflict-free over the position index as in k_small16);
+// the arrays are PSTR elements apart with PSTR = 17 (mod 32): lanes that differ in the FFT index c (the
+// fastest lane index of every stage after the first) then hit distinct banks for b64 writes (16-lane groups)
+// and b64 reads (32-lane groups).  With PSTR = L + L/16 (a multiple of 16 for L >= 256) those accesses were
+// 8- to 16-way bank conflicts.
 // ---------------------------------------------------------------------------
-// POL: cache policy of the global accesses (measured on the 2^20 pipeline: `nt` on user-buffer accesses and
-// write-through `sc1` ring stores): 0 = default everywhere, 1 = first pass (user buffer -> ring: loads nt,
-// stores sc1), 2 = ring -> ring (stores sc1), 3 = last pass (ring -> user buffer: stores nt)
-template <int LGL, int DIR, int MODE, bool BUF, int POL>
-__global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
+// ROLE: cache policy of the global accesses (measured on the 2^20 pipeline: `nt` on user-buffer accesses and
+// write-through `sc1` ring stores): ROLE_FIRST (user buffer -> ring: loads nt, stores sc1), ROLE_MIDDLE
+// (ring -> ring: stores sc1), ROLE_LAST (ring -> user buffer: stores nt); BUF = false has no policy bits.
+constexpr uint32_t tile_pstr(uint32_t L)
+{
+    uint32_t p = L + L / 16;
+    while (p % 32 != 17) ++p;
+    return p;
+}
+
+template <int LGL, int CW, int DIR, int MODE, bool BUF, int ROLE>
+__global__ __launch_bounds__(((1 << LGL) / 16) * CW) void k_tile(TileArgs a)
 {
     constexpr int L = 1 << LGL;
     constexpr int TPX = L / 16;
     constexpr int NS16 = LGL / 4;
     constexpr int RL = 1 << (LGL % 4);
-    constexpr int PADN = L + L / 16;
-    constexpr int AOUT = (POL == 1 || POL == 2) ? AUX_SC1 : (POL == 3 ? AUX_NT : AUX_DEFAULT);
+    constexpr int PSTR = tile_pstr(L);
+    constexpr int AOUT = (ROLE == ROLE_FIRST || ROLE == ROLE_MIDDLE) ? AUX_SC1 : (ROLE == ROLE_LAST ? AUX_NT : AUX_DEFAULT);
+    constexpr int AIN = (ROLE == ROLE_FIRST) ? AUX_NT : AUX_DEFAULT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f *lds_all = reinterpret_cast<v2f *>(smem);
     auto pad = [](uint32_t p) { return p + (p >> 4); };
 
-    const uint32_t tile = blockIdx.x % a.tile_count;
-    const uint32_t rest = blockIdx.x / a.tile_count;
+    // XCD-aware block -> tile mapping: each XCD gets a contiguous run of tiles (see kernels_1m.hip xcd_block)
+    const uint32_t bid = a.xcd_swizzle ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t tile = bid % a.tile_count;
+    const uint32_t rest = bid / a.tile_count;
     const uint32_t d1 = rest % a.d1_count;
     const uint64_t b = rest / a.d1_count;
     const v2f *in = a.in + b * a.in_sb + d1 * a.in_s1 + tile * a.in_st;
     v2f *out = a.out + b * a.out_sb + d1 * a.out_s1 + tile * a.out_st;
 
-    // mapping B (FFT index fastest): coalesces every access whose 16 FFTs are adjacent in memory
-    const uint32_t cB = threadIdx.x & 15, tB = threadIdx.x >> 4;
+    // mapping B (FFT index fastest): coalesces every access whose CW FFTs are adjacent in memory
+    const uint32_t cB = threadIdx.x & (CW - 1), tB = threadIdx.x / CW;
     // mapping A (position fastest): coalesces along a contiguous row
     const uint32_t cA = threadIdx.x / TPX, tA = threadIdx.x % TPX;
     const uint32_t c0 = (MODE == TILE_COLS) ? cB : cA, t0 = (MODE == TILE_COLS) ? tB : tA;
@@ -54,11 +69,11 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
 
     // stage 0: global -> LDS (L >= 64, so there is always a later stage); inputs i = t0 + m*L/16
     {
-        v2f *lds = lds_all + c0 * PADN;
+        v2f *lds = lds_all + c0 * PSTR;
         v2f x[16];
         static_for<0, 16>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
-            if constexpr (BUF) x[m] = buf_load<(POL == 1 ? AUX_NT : AUX_DEFAULT)>(rin, vin, m * sin_step);
+            if constexpr (BUF) x[m] = buf_load<AIN>(rin, vin, m * sin_step);
             else x[m] = (MODE == TILE_COLS) ? in[(uint64_t)(t0 + m * (L / 16)) * a.pitch + c0]
                                             : in[(uint64_t)c0 * a.pitch + t0 + m * (L / 16)];
         });
@@ -70,14 +85,14 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
             lds[t0 * 17 + q] = v;  // pad(t0*16 + q) = t0*16 + q + t0
         });
     }
-    v2f *lds = lds_all + cB * PADN;
+    v2f *lds = lds_all + cB * PSTR;
     const uint32_t t = tB;
     // Four-step twiddle (COLS).  Every output of this thread has index o = t + m*TPX, m = 0..15, so
     // W_T^{col*o} = [W^{col*t} * (W^{col*TPX})^(m&3)] * W^{col*TPX*4*(m>>2)}: four table look-ups
     // (hi[e>>10]*lo[e&1023] each) and short products instead of one look-up pair per output.
     v2f pa[4], pb[4];
     if constexpr (MODE == TILE_COLS) {
-        const uint32_t col = (a.flags & 1) ? 0u : tile * 16 + cB;  // flags&1: timing-only, all twiddles = 1
+        const uint32_t col = tile * CW + cB;
         auto look = [&](uint32_t e) { return cmul(a.tw_hi[e >> 10], a.tw_lo[e & 1023]); };
         const v2f wt = look(col * t), p1 = look(col * TPX);
         pa[0] = v2f{1.f, 0.f}; pa[1] = look(col * (4 * TPX)); pa[2] = look(col * (8 * TPX)); pa[3] = cmul(pa[2], pa[1]);
@@ -141,186 +156,84 @@ __global__ __launch_bounds__((1 << LGL)) void k_tile16(TileArgs a)
     }
 }
 
-template <int DIR, int MODE, bool BUF, int POL>
-static const void *tile16_kernel_p(uint32_t lg_l)
+bool tile_supported(uint32_t lg_l, uint32_t cw)
+{
+    return (cw == 16 && lg_l >= 6 && lg_l <= 10) || (cw == 32 && lg_l >= 6 && lg_l <= 9);
+}
+
+template <int CW, int DIR, int MODE, bool BUF, int ROLE>
+static const void *tile_kernel_p(uint32_t lg_l)
 {
     switch (lg_l) {
-        case 6: return reinterpret_cast<const void *>(&k_tile16<6, DIR, MODE, BUF, POL>);
-        case 7: return reinterpret_cast<const void *>(&k_tile16<7, DIR, MODE, BUF, POL>);
-        case 8: return reinterpret_cast<const void *>(&k_tile16<8, DIR, MODE, BUF, POL>);
-        case 9: return reinterpret_cast<const void *>(&k_tile16<9, DIR, MODE, BUF, POL>);
-        case 10: return reinterpret_cast<const void *>(&k_tile16<10, DIR, MODE, BUF, POL>);
+        case 6: return reinterpret_cast<const void *>(&k_tile<6, CW, DIR, MODE, BUF, ROLE>);
+        case 7: return reinterpret_cast<const void *>(&k_tile<7, CW, DIR, MODE, BUF, ROLE>);
+        case 8: return reinterpret_cast<const void *>(&k_tile<8, CW, DIR, MODE, BUF, ROLE>);
+        case 9: return reinterpret_cast<const void *>(&k_tile<9, CW, DIR, MODE, BUF, ROLE>);
+        case 10:
+            if constexpr (CW == 16) return reinterpret_cast<const void *>(&k_tile<10, CW, DIR, MODE, BUF, ROLE>);
+            else return nullptr;
         default: return nullptr;
     }
 }
-// COLS passes come as first (policy 1) or middle (2) pass, ROWS_T is always the last (3); the 64-bit-pointer
-// fallback (BUF = false, only above 4-GiB tiles) has no policy bits.  pol 0 = default policies (A/B timing).
-template <int DIR, int MODE>
-static const void *tile16_kernel(uint32_t lg_l, bool buf, int pol)
+// COLS passes come as first or middle pass, ROWS_T is always the last; the 64-bit-pointer form (BUF = false,
+// only above 4-GiB tiles) has no policy bits.
+template <int CW, int DIR, int MODE>
+static const void *tile_kernel_m(uint32_t lg_l, bool buf, int role)
 {
-    if (!buf) return tile16_kernel_p<DIR, MODE, false, 0>(lg_l);
+    if (!buf) return tile_kernel_p<CW, DIR, MODE, false, 0>(lg_l);
     if constexpr (MODE == TILE_COLS) {
-        if (pol == 1) return tile16_kernel_p<DIR, MODE, true, 1>(lg_l);
-        if (pol == 2) return tile16_kernel_p<DIR, MODE, true, 2>(lg_l);
-        return tile16_kernel_p<DIR, MODE, true, 0>(lg_l);
+        if (role == ROLE_MIDDLE) return tile_kernel_p<CW, DIR, MODE, true, ROLE_MIDDLE>(lg_l);
+        return tile_kernel_p<CW, DIR, MODE, true, ROLE_FIRST>(lg_l);
     } else {
-        if (pol == 3) return tile16_kernel_p<DIR, MODE, true, 3>(lg_l);
-        return tile16_kernel_p<DIR, MODE, true, 0>(lg_l);
+        return tile_kernel_p<CW, DIR, MODE, true, ROLE_LAST>(lg_l);
     }
 }
-static size_t tile16_lds(uint32_t lg_l) { return (size_t)16 * ((1u << lg_l) + (1u << lg_l) / 16) * sizeof(v2f); }
-
-// called at plan creation: raises the dynamic-LDS limit of the kernels a plan will launch (L >= 512)
-hipError_t prepare_tile16(uint32_t lg_l)
+static const void *tile_kernel(int dir, int mode, uint32_t cw, uint32_t lg_l, bool buf, int role)
 {
-    const size_t lds = tile16_lds(lg_l);
+    if (!tile_supported(lg_l, cw)) return nullptr;
+#define FWA_TK(CWV)                                                                                          \
+    (dir == FWD ? (mode == TILE_COLS ? tile_kernel_m<CWV, FWD, TILE_COLS>(lg_l, buf, role)                   \
+                                     : tile_kernel_m<CWV, FWD, TILE_ROWS_T>(lg_l, buf, role))                \
+                : (mode == TILE_COLS ? tile_kernel_m<CWV, INV, TILE_COLS>(lg_l, buf, role)                   \
+                                     : tile_kernel_m<CWV, INV, TILE_ROWS_T>(lg_l, buf, role)))
+    return cw == 16 ? FWA_TK(16) : FWA_TK(32);
+#undef FWA_TK
+}
+static size_t tile_lds(uint32_t lg_l, uint32_t cw) { return (size_t)cw * tile_pstr(1u << lg_l) * sizeof(v2f); }
+
+// called at plan creation: raises the dynamic-LDS limit of the kernels a plan will launch
+hipError_t prepare_tile(uint32_t lg_l, uint32_t cw)
+{
+    if (!tile_supported(lg_l, cw)) return hipErrorInvalidValue;
+    const size_t lds = tile_lds(lg_l, cw);
     if (lds <= 65536) return hipSuccess;
-    const void *ks[14] = {
-        tile16_kernel<FWD, TILE_COLS>(lg_l, true, 0),  tile16_kernel<FWD, TILE_COLS>(lg_l, true, 1),
-        tile16_kernel<FWD, TILE_COLS>(lg_l, true, 2),  tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true, 0),
-        tile16_kernel<FWD, TILE_ROWS_T>(lg_l, true, 3), tile16_kernel<FWD, TILE_COLS>(lg_l, false, 0),
-        tile16_kernel<FWD, TILE_ROWS_T>(lg_l, false, 0),
-        tile16_kernel<INV, TILE_COLS>(lg_l, true, 0),  tile16_kernel<INV, TILE_COLS>(lg_l, true, 1),
-        tile16_kernel<INV, TILE_COLS>(lg_l, true, 2),  tile16_kernel<INV, TILE_ROWS_T>(lg_l, true, 0),
-        tile16_kernel<INV, TILE_ROWS_T>(lg_l, true, 3), tile16_kernel<INV, TILE_COLS>(lg_l, false, 0),
-        tile16_kernel<INV, TILE_ROWS_T>(lg_l, false, 0)};
-    for (const void *k : ks) {
-        if (!k) return hipErrorInvalidValue;
-        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    for (int dir : {FWD, INV})
+        for (int mode : {TILE_COLS, TILE_ROWS_T})
+            for (int buf = 0; buf < 2; ++buf)
+                for (int role : {ROLE_FIRST, ROLE_MIDDLE}) {
+                    const void *k = tile_kernel(dir, mode, cw, lg_l, buf != 0, role);
+                    if (!k) return hipErrorInvalidValue;
+                    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                }
     return hipSuccess;
 }
 
-template <int DIR, int MODE>
-static hipError_t launch_tile16_mode(uint32_t lg_l, const TileArgs &a, uint64_t blocks, hipStream_t st)
-{
-    if (blocks == 0) return hipSuccess;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    // 32-bit byte offsets inside one tile?  COLS: L rows of `pitch`; ROWS_T: 16 rows of `pitch` in, L outputs of out_stride
-    const uint64_t L = 1ull << lg_l;
-    const uint64_t span = (MODE == TILE_COLS) ? L * a.pitch * 8 + 128
-                                              : ((16 * a.pitch + L) * 8 > (L * a.out_stride + 16) * 8 ? (16 * a.pitch + L) * 8
-                                                                                                    : (L * a.out_stride + 16) * 8);
-    const void *k = tile16_kernel<DIR, MODE>(lg_l, span < (1ull << 32), (int)(a.flags >> 8) & 3);
-    if (!k) return hipErrorInvalidValue;
-    TileArgs copy = a;
-    void *args[] = {&copy};
-    return hipLaunchKernel(k, dim3((uint32_t)blocks), dim3(1u << lg_l), args, tile16_lds(lg_l), st);
-}
-
-hipError_t launch_tile16(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st)
+hipError_t launch_tile(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st)
 {
     const uint64_t blocks = batch * a.d1_count * a.tile_count;
-    if (dir == FWD)
-        return mode == TILE_COLS ? launch_tile16_mode<FWD, TILE_COLS>(lg_l, a, blocks, st)
-                                 : launch_tile16_mode<FWD, TILE_ROWS_T>(lg_l, a, blocks, st);
-    return mode == TILE_COLS ? launch_tile16_mode<INV, TILE_COLS>(lg_l, a, blocks, st)
-                             : launch_tile16_mode<INV, TILE_ROWS_T>(lg_l, a, blocks, st);
-}
-
-// ---------------------------------------------------------------------------
-// Large / mid-size transforms: n = R1 * R2 * M.  Strided register-radix passes split the transform into
-// R1*R2 contiguous sub-transforms of length M (M = 2^20 -> the two-pass pipeline above, M = 4096 ->
-// k_lds_small), and one digit-reversal permute restores natural order:
-//   X[k1 + R*k'] = DFT_S(sub-array k1)[k'],  sub-array k1 [n2] = W_cur^{n2 k1} * sum_{n1} x[n1*S + n2] W_R^{n1 k1}
-// (cur = R*S).  This replaces the reference's log2(n) full passes (fft4.wgsl:36-101) by 2-3 passes plus
-// the sub-transform.  Twiddle W_cur^e = hi[e >> 10] * lo[e & 1023] (two f64-derived table entries).
-// ---------------------------------------------------------------------------
-template <int R, int DIR>
-__global__ __launch_bounds__(256) void k_radix_pass(const v2f *__restrict__ in, v2f *__restrict__ out,
-                                                    const v2f *__restrict__ tw_lo, const v2f *__restrict__ tw_hi,
-                                                    uint32_t lg_s, uint64_t total /* n_sub * S */)
-{
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const uint32_t S = 1u << lg_s;
-    const uint64_t sub = g >> lg_s;
-    const uint32_t n2 = (uint32_t)(g & (S - 1));
-    const uint64_t base = sub * ((uint64_t)R << lg_s) + n2;
-    v2f x[R];
-    static_for<0, R>([&](auto j_) {
-        constexpr int j = decltype(j_)::value;
-        x[j] = in[base + ((uint64_t)j << lg_s)];
-    });
-    fft_reg<R, DIR>(x);
-    static_for<0, R>([&](auto k_) {
-        constexpr int k1 = decltype(k_)::value;
-        v2f v = x[brev<R>(k1)];
-        if constexpr (k1 != 0) {
-            const uint32_t e = n2 * (uint32_t)k1;  // < cur <= 2^30
-            const v2f w = cmul(tw_hi[e >> 10], tw_lo[e & 1023]);
-            v = cmul_tw<DIR>(v, w);
-        }
-        out[base + ((uint64_t)k1 << lg_s)] = v;
-    });
-}
-
-template <int DIR>
-static hipError_t launch_radix_pass_dir(int R, const v2f *in, v2f *out, const v2f *lo, const v2f *hi, uint32_t lg_s,
-                                        uint64_t total, hipStream_t st)
-{
-    const uint64_t blocks = (total + 255) / 256;
+    if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 g((uint32_t)blocks), b(256);
-    switch (R) {
-        case 2: hipLaunchKernelGGL((k_radix_pass<2, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
-        case 4: hipLaunchKernelGGL((k_radix_pass<4, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
-        case 8: hipLaunchKernelGGL((k_radix_pass<8, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
-        case 16: hipLaunchKernelGGL((k_radix_pass<16, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
-        case 32: hipLaunchKernelGGL((k_radix_pass<32, DIR>), g, b, 0, st, in, out, lo, hi, lg_s, total); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_radix_pass(int dir, int R, const v2f *in, v2f *out, const v2f *tw_lo, const v2f *tw_hi,
-                             uint32_t lg_s, uint64_t n_sub, hipStream_t st)
-{
-    const uint64_t total = n_sub << lg_s;
-    if (total == 0) return hipSuccess;
-    return dir == FWD ? launch_radix_pass_dir<FWD>(R, in, out, tw_lo, tw_hi, lg_s, total, st)
-                      : launch_radix_pass_dir<INV>(R, in, out, tw_lo, tw_hi, lg_s, total, st);
-}
-
-// out[t][k1 + R1*(k2 + R2*k3)] = scale * in[t][(k1*R2 + k2)*M + k3].  An Rt x M -> M x Rt transpose per
-// transform (Rt = R1*R2), tiled through LDS: a workgroup takes TK = 4096/Rt consecutive k3, reads Rt rows of
-// TK contiguous samples (coalesced) and writes one contiguous 32-KiB block (coalesced); rows are padded by one
-// element so the transposed LDS read is conflict-free.
-__global__ __launch_bounds__(256) void k_permute(const v2f *__restrict__ in, v2f *__restrict__ out, uint32_t lg_r1,
-                                                 uint32_t lg_r2, uint32_t lg_m, float scale)
-{
-    __shared__ v2f tile[4096 + 128];
-    const uint32_t lg_rt = lg_r1 + lg_r2, Rt = 1u << lg_rt;
-    const uint32_t lg_tk = 12 - lg_rt, TK = 1u << lg_tk;          // k3 per tile
-    const uint32_t tiles_per_x = 1u << (lg_m - lg_tk);
-    const uint64_t t = blockIdx.x / tiles_per_x;
-    const uint32_t k0 = (blockIdx.x % tiles_per_x) << lg_tk;
-    const v2f *src = in + (t << (lg_m + lg_rt));
-    v2f *dst = out + (t << (lg_m + lg_rt)) + ((uint64_t)k0 << lg_rt);
-    const uint32_t R1m = (1u << lg_r1) - 1;
-    for (uint32_t e = threadIdx.x; e < 4096; e += 256) {
-        const uint32_t q = e >> lg_tk, k = e & (TK - 1);           // q = k1 + R1*k2 (output digit order)
-        const uint32_t row = ((q & R1m) << lg_r2) + (q >> lg_r1);  // k1*R2 + k2 (storage order)
-        tile[q * (TK + 1) + k] = src[((uint64_t)row << lg_m) + k0 + k];
-    }
-    __syncthreads();
-    for (uint32_t o = threadIdx.x; o < 4096; o += 256) {
-        const uint32_t k = o >> lg_rt, q = o & (Rt - 1);
-        dst[o] = tile[q * (TK + 1) + k] * scale;
-    }
-}
-
-hipError_t launch_permute(const v2f *in, v2f *out, uint32_t lg_r1, uint32_t lg_r2, uint32_t lg_m, uint64_t batch,
-                          float scale, hipStream_t st)
-{
-    if (batch == 0) return hipSuccess;
-    const uint32_t lg_rt = lg_r1 + lg_r2;
-    if (lg_rt < 1 || lg_rt > 10 || lg_m + lg_rt < 12) return hipErrorInvalidValue;  // TK = 4096/Rt must divide M
-    const uint64_t blocks = batch << (lg_m + lg_rt - 12);
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_permute, dim3((uint32_t)blocks), dim3(256), 0, st, in, out, lg_r1, lg_r2, lg_m, scale);
-    return hipGetLastError();
+    // 32-bit byte offsets inside one tile?  COLS: L rows of `pitch`; ROWS_T: cw rows of `pitch` in, L outputs of out_stride
+    const uint64_t L = 1ull << lg_l, cw = a.cw;
+    const uint64_t span_in = (cw * a.pitch + L) * 8, span_out = (L * a.out_stride + cw) * 8;
+    const uint64_t span = (mode == TILE_COLS) ? L * a.pitch * 8 + cw * 8 : (span_in > span_out ? span_in : span_out);
+    const void *k = tile_kernel(dir, mode, a.cw, lg_l, span < (1ull << 32), (int)a.role);
+    if (!k) return hipErrorInvalidValue;
+    TileArgs copy = a;
+    if (blocks % 8) copy.xcd_swizzle = 0;
+    void *args[] = {&copy};
+    return hipLaunchKernel(k, dim3((uint32_t)blocks), dim3((uint32_t)((L / 16) * cw)), args, tile_lds(lg_l, a.cw), st);
 }
 
 }  // namespace fwa

@@ -6,7 +6,10 @@ C ABI.  Names and call order follow the reference so that the example loop
     out = plan.proc(enc); enc.copy_buffer_to_buffer(out, 0, staging, 0, n);
     queue.submit(enc.finish()); staging.map_read()
 
-reads the same here.
+reads the same here.  Ordering follows the reference too: work recorded on an
+encoder runs on that encoder's HIP stream; ``device.poll()`` (``Maintain::wait``,
+examples/basic.rs:106) and a ``map_read()`` without a stream wait for ALL work
+submitted to the device, so the literal sequence above never reads stale bytes.
 """
 import ctypes
 
@@ -40,6 +43,8 @@ class Buffer:
         """map_async + poll(wait) + get_mapped_range (examples/basic.rs:105-122): blocking read-back."""
         size = self.size - offset if size is None else size
         out = np.empty(size // np.dtype(dtype).itemsize, dtype=dtype)
+        if stream is None:
+            self.device.poll()  # map_async + poll(wait): everything submitted so far, on any encoder, has finished
         st = _ffi.lib().fwa_buf_download(out.ctypes.data_as(ctypes.c_void_p), self._h, offset, size,
                                          stream._h if stream else None)
         _ffi.check(st, self.device._h, "fwa_buf_download")
@@ -170,8 +175,20 @@ class Device:
         return CommandEncoder(self, h, owned=True)
 
     def poll(self, encoder=None):
-        """device.poll(Maintain::wait()) (examples/basic.rs:106)."""
-        (encoder or self._default).synchronize()
+        """device.poll(Maintain::wait()) (examples/basic.rs:106): all submitted work (or one encoder's)."""
+        if encoder is not None:
+            encoder.synchronize()
+        else:
+            _ffi.check(_ffi.lib().fwa_ctx_synchronize(self._h), self._h, "fwa_ctx_synchronize")
+
+    def stats(self):
+        """Plan-cache counters of this context (fwa_ctx_get_i64)."""
+        out = {}
+        for k in ("table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "last_plan_create_us"):
+            v = ctypes.c_int64()
+            _ffi.check(_ffi.lib().fwa_ctx_get_i64(self._h, k.encode(), ctypes.byref(v)), self._h, "fwa_ctx_get_i64")
+            out[k] = v.value
+        return out
 
     def pinned_array(self, n_elements, dtype=np.complex64):
         """Page-locked host staging array (the reference's MAP_READ staging buffer, examples/basic.rs:50-55)."""

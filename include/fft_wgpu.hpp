@@ -72,6 +72,8 @@ public:
     }
     void read(void *host, uint64_t bytes, CommandEncoder *e = nullptr) const  // map_async + poll + get_mapped_range
     {
+        // without an encoder: device.poll(Maintain::wait()) semantics, all submitted work has finished first
+        if (!e) d_->check(fwa_ctx_synchronize(d_->raw()), "fwa_ctx_synchronize");
         d_->check(fwa_buf_download(host, h_, 0, bytes, e ? e->raw() : nullptr), "fwa_buf_download");
     }
 

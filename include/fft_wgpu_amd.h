@@ -17,7 +17,8 @@
  *
  * Threading: ctx / plan creation and destruction are not thread-safe.
  * One in-flight fwa_plan_exec per plan (plans own scratch).  One ctx per
- * device ordinal; multi-GPU = one process (or one ctx) per device.
+ * device ordinal; multi-GPU = one process (or one ctx) per device: every
+ * entry point makes its context's device current before it touches HIP.
  *
  * Errors: every function returns an fwa_status (0 = ok).  Nothing aborts or
  * throws across the ABI.  fwa_last_error_string() gives detail.
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FWA_ABI_VERSION 1
+#define FWA_ABI_VERSION 2
 
 typedef enum fwa_status {
     FWA_OK = 0,
@@ -69,6 +70,14 @@ const char *fwa_status_string(int32_t status);
 int32_t fwa_device_count(int32_t *count);
 int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out);
 int32_t fwa_ctx_destroy(fwa_ctx *ctx);
+/* device.poll(Maintain::wait()) (examples/basic.rs:106): returns once ALL work submitted to this device, on
+ * any stream, has completed. */
+int32_t fwa_ctx_synchronize(fwa_ctx *ctx);
+/* Context counters (no reference analogue).  Keys: "device"; plan cache (tables of a transform length are
+ * built once per context and shared by every later plan of that length; ring allocations of destroyed plans
+ * are reused): "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses"; "last_plan_create_us"
+ * (wall time of the most recent fwa_plan_create). */
+int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value);
 /* name: NUL-terminated gcnArchName ("gfx950:..."), truncated to name_cap. */
 int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap,
                             int32_t *compute_units, uint64_t *hbm_bytes);
@@ -131,16 +140,25 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
 int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result);
 int32_t fwa_plan_destroy(fwa_plan *plan);
 
-/* Pure host logic, no device needed: which path and factorisation a plan of length fft_len uses.
+/* Pure host logic, no device needed: which path and factorisation a plan of length fft_len uses (for a batch
+ * of at least 4 transforms; at n = 2^20 smaller batches take the tiled path, see "factors").
  * *path as in fwa_plan_get_i64("path"); log2_factors[0..2] = log2 of the per-pass FFT lengths
  * (0 = unused), e.g. 2^20 -> {10,10,0}, 2^24 -> {8,8,8}, 512 -> {9,0,0}. */
 int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors[3]);
 
-/* Introspection / tuning (no reference analogue).  Keys for fwa_plan_get_i64:
- *   "batch", "fft_len", "path" (0 lds-small, 1 two-launch 2^20, 2 radix-2 global, 3 normalize, 4 identity,
- *   5 fused in-place 2^20), "launches_per_exec", "scratch_bytes", "group", "streams" (two-launch path),
- *   "depth", "wgs" (fused path), "device_error" (synchronises; non-zero = a bounded device spin timed out).
- * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "depth", "wgs", "path". */
+/* Introspection / tuning (no reference analogue).  No key changes what a plan computes.
+ * Keys for fwa_plan_get_i64:
+ *   "batch", "fft_len",
+ *   "path": 0 one-launch kernels (n <= 16384), 1 two-pass 2^20 pipeline, 2 literal radix-2 recurrence (one
+ *           launch per stage, kernel/fft.wgsl:27-62; forced only), 3 normalize, 4 identity (n = 1),
+ *           7 tiled 2-3 pass pipeline (2^15..2^19, 2^21..2^30, and 2^20 with fewer than 4 transforms),
+ *   "factors": log2(N1) | log2(N2) << 8 | log2(N3) << 16 of a multi-pass plan,
+ *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's tables),
+ *   "group" (transforms per launch), "streams" (internal streams the groups alternate over),
+ *   "tile_w" (2^20 path: 16 or 32 columns per tile), "cw" (tiled path: 16 or 32 FFTs per workgroup),
+ *   "small_reg" (n <= 16384: 1 register radix-16 kernels, 0 LDS radix-2 kernel, 2 wave-shuffle exchange).
+ * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "tile_w", "cw", "factors",
+ * "small_reg", "path" (value 2 only). */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     # and the ctypes table covers the header exactly
     assert sorted(_ffi._SIGNATURES) == names
-    assert L.fwa_abi_version() == 1
+    assert L.fwa_abi_version() == 2
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -75,3 +75,31 @@ def test_world_size_2_gloo_scatter_transform_gather(batch):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher starts its own ranks; with fewer than N devices visible it must
+    exit non-zero instead of reporting an N-GPU figure from fewer GPUs (here: no GPU at all)."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "visible" in r.stderr
+    assert '"n_gpus"' not in r.stdout           # no benchmark line was produced
+    # a launcher environment that disagrees with --gpus is rejected as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_rank_slab_is_sharding_slab():
+    """bench.py gives rank r the transforms sharding.slab(batch * world, r, world): config C4 = 4096 per GPU x 8."""
+    from fft_wgpu_amd.sharding import slab
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "sharding.slab(batch * world, rank, world)" in src
+    for world in (1, 2, 4, 8):
+        for r in range(world):
+            assert slab(4096 * world, r, world) == (r * 4096, (r + 1) * 4096)

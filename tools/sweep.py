@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """tools/sweep.py -- GPU-side tuning sweep (not part of the product path or the tests).
 
-Measures (HIP events, median of a few repetitions):
-  * float4 copy rate vs footprint (what the Infinity Cache serves vs HBM),
-  * the N=2^20 plan at several (group, streams) settings.
-Writes one JSON line per measurement to stdout.
+Times Forward.proc (HIP events on the launch stream, median of --reps) for a list of plan settings, all in ONE
+process on ONE device with the variants interleaved round-robin (cdna_hip_programming.md rule 24).
+A setting is "key=value,key=value" over the plan's tunables (group, streams, tile_w, cw, factors); factors may be
+written as 9.9 or 6.6.6.  One JSON line per setting.
+
+  python tools/sweep.py --lg 20 --batch 4096 --set "tile_w=16" --set "tile_w=32" --set "tile_w=32,group=8"
 """
 import argparse
 import json
@@ -15,28 +17,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fft_wgpu_amd as fw  # noqa: E402
 
 
-def med(xs):
-    xs = sorted(xs)
-    return xs[len(xs) // 2]
+def parse_setting(s):
+    out = {}
+    for kv in [p for p in s.split(",") if p]:
+        k, v = kv.split("=")
+        if k == "factors":
+            f = [int(t) for t in v.split(".")] + [0]
+            out[k] = f[0] | (f[1] << 8) | (f[2] << 16)
+        else:
+            out[k] = int(v)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--lg", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--settings", type=str, default="8x2", help="two-launch path: GROUPxSTREAMS,...")
-    ap.add_argument("--mix", type=str, default="", help="mixed-launch two-pass path: GROUPxSTREAMSxDBGxPOLICY,...")
-    ap.add_argument("--fused", type=str, default="4x512,2x512,3x512,6x512,8x512,12x512,4x256,4x384",
-                    help="fused path: DEPTHxWORKGROUPS,...")
-    ap.add_argument("--copy", action="store_true")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--set", action="append", default=[], help="one plan setting (repeatable); '' = defaults")
+    ap.add_argument("--copy", action="store_true", help="float4 copy rate vs footprint first")
     args = ap.parse_args()
     dev, queue = fw.prepare_gpu(0)
-    n = 1 << 20
+    n = 1 << args.lg
     nbytes = n * args.batch * 8
     buf = dev.create_buffer(nbytes)
     enc = dev.create_command_encoder()
-    dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
-    enc.synchronize()
+    scale = 2.0 ** -40
 
     if args.copy:
         for mib in (8, 16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 4096):
@@ -56,44 +62,37 @@ def main():
             ms = a.elapsed_ms(b) / iters
             print(json.dumps({"what": "copy", "footprint_MiB": 2 * mib, "us": ms * 1e3,
                               "GBps_rw": 2 * half / (ms * 1e-3) / 1e9}), flush=True)
-        dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
-        enc.synchronize()
 
-    runs = ([("two", s) for s in args.settings.split(",") if s] + [("mix", s) for s in args.mix.split(",") if s]
-            + [("fused", s) for s in args.fused.split(",") if s])
-    for kind, s in runs:
-        parts = [int(v) for v in s.split("x")]
-        g, ns = parts[0], parts[1]
-        dbg = parts[2] if len(parts) > 2 else 0
-        pol = parts[3] if len(parts) > 3 else 0
+    settings = args.set or [""]
+    plans = []
+    for s in settings:
         plan = fw.Forward(dev, queue, buf, n)
-        if kind in ("two", "mix"):
-            plan.set("path", 1)
-            plan.set("mix", 1 if kind == "mix" else 0)
-            plan.set("group", g)
-            plan.set("streams", ns)
-        else:
-            plan.set("depth", g)
-            plan.set("wgs", ns)
-            if dbg:
-                plan.set("dbg", dbg)
-        plan.set("policy", pol)
-        dev.fill_synthetic(buf, n, scale=2.0 ** -40, encoder=enc)
-        plan.proc(enc)
-        enc.synchronize()
-        times = []
-        for _ in range(args.reps):
+        kv = parse_setting(s)
+        for key in ("path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "wgs"):
+            if key in kv:
+                plan.set(key, kv[key])
+        plans.append((s, plan, []))
+    # one regeneration of the input per round: log2(n) <= 30 bits of growth per exec, 2^-40 input scale and at most
+    # 3 execs between refills keep fp32 finite
+    for r in range(args.reps + 1):
+        for i, (s, plan, times) in enumerate(plans):
+            if i % 3 == 0:
+                dev.fill_synthetic(buf, n, scale=scale, encoder=enc)
             a, b = fw.Event(dev), fw.Event(dev)
             a.record(enc)
             plan.proc(enc)
             b.record(enc)
-            times.append(a.elapsed_ms(b))
-        ms = med(times)
-        err = plan.get("device_error")
-        print(json.dumps({"what": "fft1m_" + kind, "a": g, "b": ns, "dbg": dbg, "policy": pol, "device_error": err, "batch": args.batch, "ms": ms,
-                          "ms_all": times, "Gsamples_s": n * args.batch / (ms * 1e-3) / 1e9,
-                          "roofline_frac": 16 * n * args.batch / (ms * 1e-3) / 8e12}), flush=True)
-        plan.destroy()
+            ms = a.elapsed_ms(b)
+            if r:
+                times.append(ms)
+    for s, plan, times in plans:
+        ms = sorted(times)[len(times) // 2]
+        print(json.dumps({"what": "fft", "lg_n": args.lg, "batch": args.batch, "setting": s or "(default)",
+                          "path": plan.get("path"), "factors": plan.get("factors"), "group": plan.get("group"),
+                          "streams": plan.get("streams"), "tile_w": plan.get("tile_w"), "cw": plan.get("cw"), "xcd_swizzle": plan.get("xcd_swizzle"),
+                          "ms": round(ms, 4), "ms_min": round(min(times), 4), "ms_all": [round(t, 4) for t in times],
+                          "Gsamples_s": round(n * args.batch / (ms * 1e-3) / 1e9, 2),
+                          "roofline_frac": round(16 * n * args.batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
 
 
 if __name__ == "__main__":
