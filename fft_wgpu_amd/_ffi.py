@@ -65,6 +65,8 @@ _SIGNATURES = {
     "fwa_plan_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
     "fwa_event_create": (_I32, [_P, _PP]),
     "fwa_event_record": (_I32, [_P, _P]),
+    "fwa_event_synchronize": (_I32, [_P]),
+    "fwa_stream_wait_event": (_I32, [_P, _P]),
     "fwa_event_elapsed_ms": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "fwa_event_destroy": (_I32, [_P]),
     "fwa_fill_synthetic": (_I32, [_P, _U64, _U64, _U32, ctypes.c_float, _P]),

@@ -1122,6 +1122,20 @@ int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream)
     HIP_TRY(ev->ctx, hipEventRecord(ev->e, raw(stream)));
     return FWA_OK;
 }
+int32_t fwa_event_synchronize(fwa_event *ev)
+{
+    if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    USE_DEVICE(ev->ctx);
+    HIP_TRY(ev->ctx, hipEventSynchronize(ev->e));
+    return FWA_OK;
+}
+int32_t fwa_stream_wait_event(fwa_stream *stream, fwa_event *ev)
+{
+    if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    USE_DEVICE(ev->ctx);
+    HIP_TRY(ev->ctx, hipStreamWaitEvent(raw(stream), ev->e, 0));
+    return FWA_OK;
+}
 int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms)
 {
     if (!start || !end || !ms) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");

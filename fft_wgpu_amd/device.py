@@ -76,6 +76,10 @@ class CommandEncoder:
         """Device-side dependency: work recorded here after this call runs after everything on `other`."""
         _ffi.check(_ffi.lib().fwa_stream_wait_stream(self._h, other._h), self.device._h, "fwa_stream_wait_stream")
 
+    def wait_event(self, event):
+        """Device-side dependency on one recorded point (an Event) of another encoder."""
+        _ffi.check(_ffi.lib().fwa_stream_wait_event(self._h, event._h), self.device._h, "fwa_stream_wait_event")
+
     def synchronize(self):
         _ffi.check(_ffi.lib().fwa_stream_synchronize(self._h), self.device._h, "fwa_stream_synchronize")
 
@@ -100,6 +104,9 @@ class Event:
 
     def record(self, encoder):
         _ffi.check(_ffi.lib().fwa_event_record(self._h, encoder._h), self.device._h, "fwa_event_record")
+
+    def synchronize(self):
+        _ffi.check(_ffi.lib().fwa_event_synchronize(self._h), self.device._h, "fwa_event_synchronize")
 
     def elapsed_ms(self, end):
         ms = ctypes.c_float()

@@ -165,6 +165,11 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 /* ---- measurement helpers (HIP events on the launch stream) -------------- */
 int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out);
 int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream);
+/* Host waits for the work recorded before `ev`. */
+int32_t fwa_event_synchronize(fwa_event *ev);
+/* Device-side dependency on ONE recorded point of another stream (fwa_stream_wait_stream waits for everything
+ * enqueued so far): what the pipelined form of the reference's loop (examples/basic.rs:72-127) needs per slot. */
+int32_t fwa_stream_wait_event(fwa_stream *stream, fwa_event *ev);
 /* Blocks until `end` has completed. */
 int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms);
 int32_t fwa_event_destroy(fwa_event *ev);

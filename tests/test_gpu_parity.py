@@ -422,6 +422,70 @@ def test_config_c3_full_size_sampled(gpu, oracle):
         assert mx <= REL_TOL
 
 
+# ---- the reference's benchmark loop, pipelined over two streams with pinned staging ----
+@pytest.mark.parametrize("slots", [2, 3])
+def test_host_transfer_pipeline_matches_oracle(gpu, oracle, slots):
+    """examples/basic.rs:72-127 (write_buffer -> proc -> copy_buffer_to_buffer -> read back, every iteration) through
+    fft_wgpu_amd.HostPipeline: upload of iteration i+1, transform of i and read-back of i-1 overlap.  Every iteration
+    gets different data and EVERY read-back sample is compared with the oracle."""
+    fw, dev, queue = gpu
+    n, batch = 512, 2500                                   # the reference's own benchmark shape (basic.rs:32,66)
+    count = n * batch
+    pipe = fw.HostPipeline(dev, queue, lambda d, q, b: fw.Forward(d, q, b, n), count, slots=slots)
+    iters = 7
+    inputs = [oracle.gen_input(n, batch, first_transform=1000 * it) for it in range(iters)]
+    results = {}
+    pending = []
+    for it in range(iters):
+        s = pipe.submit(inputs[it])
+        pending.append((it, s))
+        if len(pending) == slots:                          # read a slot back before it is reused
+            j, sj = pending.pop(0)
+            results[j] = pipe.result(sj).copy()
+    for j, sj in pending:
+        results[j] = pipe.result(sj).copy()
+    pipe.drain()
+    for it in range(iters):
+        r = oracle.dft_f64(inputs[it], n, -1)
+        _check(oracle, results[it], r, n)
+    # the serial form of the same loop (the reference's literal call order, default-stream read-back) agrees bit for bit
+    src = dev.create_buffer(count * 8)
+    staging = dev.create_buffer(count * 8)
+    plan = fw.Forward(dev, queue, src, n)
+    queue.write_buffer(src, 0, inputs[3])
+    enc = dev.create_command_encoder()
+    out = plan.proc(enc)
+    enc.copy_buffer_to_buffer(out, 0, staging, 0, count * 8)
+    queue.submit(enc.finish())
+    ans = staging.map_read()                                # no stream given: device.poll(wait) semantics
+    assert np.array_equal(ans.view(np.uint32), results[3].view(np.uint32))
+
+
+def test_plan_cache_shares_tables_and_rings(gpu):
+    """Second plan of a length on the same context: no table build, no upload; a destroyed plan's ring is reused
+    (examples/basic_inverse2.rs creates two plans per size)."""
+    fw, dev, queue = gpu
+    n = 1 << 20
+    buf = dev.create_buffer(n * 8 * 8)
+    buf2 = dev.create_buffer(n * 8 * 8)
+    before = dev.stats()
+    p1 = fw.Forward(dev, queue, buf, n)
+    mid = dev.stats()
+    p2 = fw.Inverse(dev, queue, buf2, n)                    # tables hold forward twiddles; the inverse conjugates on use
+    after = dev.stats()
+    assert mid["table_builds"] - before["table_builds"] <= 1
+    assert after["table_builds"] == mid["table_builds"] and after["table_cache_hits"] == mid["table_cache_hits"] + 1
+    assert p2.get("tables_shared") >= 2                     # the cache and p1
+    first_us, second_us = mid["last_plan_create_us"], after["last_plan_create_us"]
+    print("plan create 2^20: first %d us, second (cached tables) %d us" % (first_us, second_us))
+    p1.destroy()
+    p3 = fw.Forward(dev, queue, buf, n)
+    end = dev.stats()
+    assert end["ring_reuses"] == after["ring_reuses"] + 1 and end["ring_allocs"] == after["ring_allocs"]
+    print("plan create 2^20 with cached tables and pooled ring: %d us" % end["last_plan_create_us"])
+    p2.destroy(); p3.destroy()
+
+
 # ---- error behaviour of the boundary ----
 def test_rejects_bad_arguments(gpu):
     fw, dev, queue = gpu

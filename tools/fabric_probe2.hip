@@ -80,6 +80,14 @@ int main(int argc, char **argv)
         {"sc0sc1 big stores             ", k_probe<0, 17, 0, 0>},
         {"nt big ld, sc0sc1 big st      ", k_probe<2, 17, 0, 0>},
         {"sc1 nt big stores             ", k_probe<0, 18, 0, 0>},
+        {"sc1|nt big ld, nt st, sc1 sm  ", k_probe<18, 2, 16, 16>},
+        {"sc0sc1nt big ld, nt st, sc1 sm", k_probe<19, 2, 16, 16>},
+        {"sc0sc1 big ld, nt st, sc1 sm  ", k_probe<17, 2, 16, 16>},
+        {"sc0|nt big ld, nt st, sc1 sm  ", k_probe<3, 2, 16, 16>},
+        {"sc1 big ld, nt st, sc1 sm     ", k_probe<16, 2, 16, 16>},
+        {"nt big, sc1|nt small st       ", k_probe<2, 2, 16, 18>},
+        {"nt big, sc0sc1nt small st     ", k_probe<2, 2, 16, 19>},
+        {"nt big, plain small           ", k_probe<2, 2, 0, 0>},
     };
     int modes[] = {3, 12, 15, 9, 6};
     const char *mn[] = {"copy big", "copy small", "FFT mix(15)", "rd big+wr small", "wr big+rd small"};

@@ -3,7 +3,8 @@
 batch 2500, all-ones input; every iteration uploads the batch, runs Forward.proc, copies the result to a
 staging buffer and reads it back.  Measured two ways through the C ABI:
   serial    -- the reference's sequence, one blocking iteration after another;
-  pipelined -- pinned staging + three streams (upload / transform / download) with double buffering.
+  pipelined -- fft_wgpu_amd.HostPipeline: pinned staging, upload + transform on one stream, read-back on a second,
+               double or triple buffering.
 Reports iterations/s and the PCIe-inclusive sample rate (this is NOT bench.py's `value`)."""
 import argparse
 import json
@@ -47,35 +48,26 @@ def main():
                       "iters_per_s": args.iters / dt, "Gsamples_s_pcie_inclusive": count * args.iters / dt / 1e9,
                       "host_link_GBps_each_way": nbytes * args.iters / dt / 1e9}), flush=True)
 
-    # ---- pipelined: pinned staging, double buffering, three streams
-    up, ex, down = (dev.create_command_encoder() for _ in range(3))
-    hin = [dev.pinned_array(count) for _ in range(2)]
-    hout = [dev.pinned_array(count) for _ in range(2)]
-    for h in hin:
-        h[:] = 1
-    bufs = [dev.create_buffer(nbytes) for _ in range(2)]
-    outs = [dev.create_buffer(nbytes) for _ in range(2)]
-    plans = [fw.Forward(dev, queue, b, n) for b in bufs]
-    for it in range(4 + args.iters):
-        if it == 4:
-            dev.poll(up); dev.poll(ex); dev.poll(down)
-            t0 = time.perf_counter()
-        s = it & 1
-        up.wait_for(ex)                                                # slot s was consumed two iterations ago
-        queue.write_buffer(bufs[s], 0, hin[s], encoder=up)
-        ex.wait_for(up)
-        ex.wait_for(down)                                              # outs[s] fully read back before reuse
-        out = plans[s].proc(ex)
-        ex.copy_buffer_to_buffer(out, 0, outs[s], 0, nbytes)
-        down.wait_for(ex)
-        dev.download_async(hout[s], outs[s], down)
-    dev.poll(up); dev.poll(ex); dev.poll(down)
-    dt = time.perf_counter() - t0
-    assert abs(hout[0][0] - n) < 1e-3 and abs(hout[1][n] - n) < 1e-3
-    print(json.dumps({"what": "reference loop, pipelined (pinned, 3 streams)", "n": n, "batch": batch,
-                      "iters": args.iters, "iters_per_s": args.iters / dt,
-                      "Gsamples_s_pcie_inclusive": count * args.iters / dt / 1e9,
-                      "host_link_GBps_each_way": nbytes * args.iters / dt / 1e9}), flush=True)
+    # ---- pipelined: pinned staging, double buffering, three streams, one event per slot and stage
+    for slots in (2, 3):
+        pipe = fw.HostPipeline(dev, queue, lambda d, q, b: fw.Forward(d, q, b, n), count, slots=slots)
+        for h in pipe.hin:
+            h[:] = 1
+        for it in range(2 * slots + args.iters):
+            if it == 2 * slots:
+                pipe.drain()
+                t0 = time.perf_counter()
+            pipe.submit()
+        pipe.drain()
+        dt = time.perf_counter() - t0
+        for s in range(slots):
+            r = pipe.result(s)
+            assert abs(r[0] - n) < 1e-3 and abs(r[n] - n) < 1e-3 and abs(r[1]) < 1e-5
+        print(json.dumps({"what": f"reference loop, pipelined (fft_wgpu_amd.HostPipeline: pinned staging, 2 streams, {slots} slots)", "n": n,
+                          "batch": batch, "iters": args.iters, "iters_per_s": args.iters / dt,
+                          "Gsamples_s_pcie_inclusive": count * args.iters / dt / 1e9,
+                          "host_link_GBps_each_way": nbytes * args.iters / dt / 1e9}), flush=True)
+        del pipe
 
 
 if __name__ == "__main__":

@@ -80,6 +80,7 @@ struct Ctl {
     uint32_t pad0[13];
     uint32_t xcc_count[16];      // workgroups per XCD
     uint32_t bar[16 * 32];       // one barrier counter per XCD, 128 B apart
+    uint32_t flags[16 * 64];     // L2-local barrier: one epoch word per workgroup, 256 B per XCD
     uint32_t t_exchange_ticks[16];
 };
 
@@ -96,6 +97,31 @@ __device__ __forceinline__ uint32_t ctr_read(uint32_t *p)
     if (L2SCOPE) return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// XCD-local barrier without atomics: every workgroup publishes its epoch with a PLAIN store (the line stays in this
+// XCD's L2), one wave polls all 64 flags with ONE sc1 (L1-bypassing, L2-served) load instruction, lane i reading the
+// flag of workgroup i.  Valid only because the 64 workgroups were grouped by HW_REG_XCC_ID (one L2).
+__device__ __forceinline__ bool flag_barrier(uint32_t *flags /* 64 words of this XCD */, uint32_t m, uint32_t epoch, uint32_t tid,
+                                             uint32_t *err)
+{
+    if (tid == 0) __hip_atomic_store(&flags[m], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store
+    bool ok = true;
+    if (tid < 64) {
+        auto r = __builtin_amdgcn_make_buffer_rsrc(flags, 0, 256, 0x00020000);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r, tid * 4, 0, SC1);
+            if (__all((int)(v - epoch) >= 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+                __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    return ok;
+}
+
 template <bool L2SCOPE>
 __device__ __forceinline__ bool spin_ge(uint32_t *p, uint32_t target, uint32_t *err)
 {
@@ -114,7 +140,8 @@ __device__ __forceinline__ bool spin_ge(uint32_t *p, uint32_t target, uint32_t *
 // hbm: 0 = exchange only; 1 = per transform: load the tile (32 x 8 B per thread, column-tile pattern) from `src`,
 // exchange, store it to `dst` in the pass-2 pattern.
 template <int R, bool L2SCOPE, int hbm, int verify>
-__global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox_all, const char *src, char *dst, uint32_t n_iter)
+__global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox_all, const char *src, char *dst, uint32_t n_iter,
+                                                         uint32_t active_xcds)
 {
     constexpr int K = 32 / R;
     __shared__ uint32_t s_info[4];
@@ -130,13 +157,17 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
     }
     __syncthreads();
     const uint32_t xcc = s_info[0], m = s_info[1];
-    if (!s_info[2]) return;
+    if (!s_info[2] || xcc >= active_xcds) return;
     const uint32_t a = m >> 1;  // pair-group
     char *mailbox = mailbox_all + (size_t)xcc * (2u * 64 * K * 2 * 2048);
     auto rmb = __builtin_amdgcn_make_buffer_rsrc(mailbox, 0, 2u * 64 * K * 2 * 2048, 0x00020000);
     uint32_t *bar = &ctl->bar[xcc * 32];
     const uint32_t half = tid >> 8, lane = tid & 255;
 
+    if (hbm == 2) {  // staggered start: XCD x begins x/8 of a 24-us cycle late, so the HBM phases of the XCDs interleave
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < 300ull * xcc) __builtin_amdgcn_s_sleep(8);
+    }
     v2u x[32];
     uint32_t barrier_no = 0;
     uint64_t ticks = 0;
@@ -167,9 +198,12 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
-                ctr_add<L2SCOPE>(bar);
-                s_info[3] = spin_ge<L2SCOPE>(bar, 64u * (barrier_no + 1), &ctl->error) ? 1u : 0u;
+            if (L2SCOPE) {
+                const bool ok = flag_barrier(&ctl->flags[xcc * 64], m, barrier_no + 1, tid, &ctl->error);
+                if (tid == 0) s_info[3] = ok ? 1u : 0u;
+            } else if (tid == 0) {
+                ctr_add<false>(bar);
+                s_info[3] = spin_ge<false>(bar, 64u * (barrier_no + 1), &ctl->error) ? 1u : 0u;
             }
             __syncthreads();
             if (!s_info[3]) return;
@@ -213,15 +247,15 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
 }
 
 template <int R, bool L2, int hbm>
-static void run_exchange(const char *name, Ctl *ctl, char *mailbox, char *a, char *b, uint32_t n_iter)
+static void run_exchange(const char *name, Ctl *ctl, char *mailbox, char *a, char *b, uint32_t n_iter, uint32_t active = 8)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f; Ctl h{};
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(ctl, 0, sizeof(Ctl)));
         CK(hipEventRecord(e0));
-        if (rep == 0 && !hbm) hipLaunchKernelGGL((k_xcd_exchange<R, L2, 0, 1>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter);
-        else hipLaunchKernelGGL((k_xcd_exchange<R, L2, hbm, 0>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter);
+        if (rep == 0 && !hbm) hipLaunchKernelGGL((k_xcd_exchange<R, L2, 0, 1>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active);
+        else hipLaunchKernelGGL((k_xcd_exchange<R, L2, hbm, 0>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpy(&h, ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
@@ -276,15 +310,24 @@ int main()
     char *mailbox; CK(hipMalloc(&mailbox, 8ull * 2 * 64 * 32 * 2 * 2048)); CK(hipMemset(mailbox, 0, 8ull * 2 * 64 * 32 * 2 * 2048));
     printf("---- part B: in-XCD exchange only (64 workgroups per XCD hold 8 MiB in registers; 8 XCDs run independent groups)\n");
     run_exchange<8, false, 0>("8 rounds x 4 regs, barrier counter: agent-scope atomics", ctl, mailbox, a, b, 64);
-    run_exchange<8, true, 0>("8 rounds x 4 regs, barrier counter: L2 atomics", ctl, mailbox, a, b, 64);
+    run_exchange<8, true, 0>("8 rounds x 4 regs, barrier: L2-local flags", ctl, mailbox, a, b, 64);
     run_exchange<4, false, 0>("4 rounds x 8 regs, barrier counter: agent-scope atomics", ctl, mailbox, a, b, 64);
-    run_exchange<4, true, 0>("4 rounds x 8 regs, barrier counter: L2 atomics", ctl, mailbox, a, b, 64);
-    run_exchange<2, true, 0>("2 rounds x 16 regs (8 MiB of mailbox > L2), L2 atomics", ctl, mailbox, a, b, 64);
-    run_exchange<16, true, 0>("16 rounds x 2 regs, barrier counter: L2 atomics", ctl, mailbox, a, b, 64);
+    run_exchange<4, true, 0>("4 rounds x 8 regs, barrier: L2-local flags", ctl, mailbox, a, b, 64);
+    run_exchange<2, true, 0>("2 rounds x 16 regs (8 MiB of mailbox > L2), L2 flags", ctl, mailbox, a, b, 64);
+    run_exchange<16, true, 0>("16 rounds x 2 regs, barrier: L2-local flags", ctl, mailbox, a, b, 64);
     printf("---- part C: HBM tile load -> exchange -> HBM tile store (whole memory skeleton, 128 transforms per XCD)\n");
-    run_exchange<8, true, 1>("8 rounds x 4 regs, L2 atomics, with HBM", ctl, mailbox, a, b, 128);
-    run_exchange<4, true, 1>("4 rounds x 8 regs, L2 atomics, with HBM", ctl, mailbox, a, b, 128);
+    run_exchange<4, true, 2>("4 rounds x 8 regs, L2 flags, with HBM, staggered XCD start", ctl, mailbox, a, b, 128);
+    run_exchange<8, true, 2>("8 rounds x 4 regs, L2 flags, with HBM, staggered XCD start", ctl, mailbox, a, b, 128);
+    run_exchange<4, false, 2>("4 rounds x 8 regs, agent atomics, with HBM, staggered", ctl, mailbox, a, b, 128);
+    run_exchange<8, true, 1>("8 rounds x 4 regs, L2 flags, with HBM", ctl, mailbox, a, b, 128);
+    run_exchange<4, true, 1>("4 rounds x 8 regs, L2 flags, with HBM", ctl, mailbox, a, b, 128);
     run_exchange<8, false, 1>("8 rounds x 4 regs, agent atomics, with HBM", ctl, mailbox, a, b, 128);
+    printf("---- part D: the same skeleton with only k XCDs active (the others exit): is the 36 us HBM contention?\n");
+    for (uint32_t k : {1u, 2u, 4u, 6u, 8u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "4 rounds, L2 flags, with HBM, %u active XCDs", k);
+        run_exchange<4, true, 1>(nm, ctl, mailbox, a, b, 128, k);
+    }
     printf("budget at 70 %% of the 8 TB/s roofline: 23.4 us per transform per XCD; two-pass pipeline today: 41.6 us\n");
     return 0;
 }
