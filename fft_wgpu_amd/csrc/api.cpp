@@ -26,7 +26,7 @@
 using fwa::v2f;
 
 enum fwa_path : int64_t {
-    PATH_SMALL = 0,       // n <= 16384: one launch (k_tiny / k_small16 / k_lds_small)
+    PATH_SMALL = 0,       // n <= 32768: one launch (k_tiny / k_small16 / k_lds_small)
     PATH_TWOPASS_1M = 1,  // n = 2^20: k_p1_1m + k_p2_1m per group of transforms
     PATH_R2_GLOBAL = 2,   // the reference recurrence literally, one launch per stage (forced only)
     PATH_NORMALIZE = 3,
@@ -166,12 +166,15 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     lf[0] = lf[1] = lf[2] = 0;
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
-    if (n <= 16384) { lf[0] = lg; return PATH_SMALL; }
+    if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
     if (n == (1u << 20) && batch >= FEW_1M) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
-        // factors of 64..1024 each: two while both stay <= 512, three otherwise (re-tunable: key "factors")
-        const uint32_t nf = lg <= 17 ? 2 : 3;
-        for (uint32_t i = 0; i < nf; ++i) lf[i] = lg / nf + (i >= nf - lg % nf ? 1 : 0);
+        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19 -- with a 1024-point first
+        // pass at 2^18 / 2^19 (measured: 2^18 as 1024 x 256 0.33 of the roofline, as 512 x 512 0.30, as 64^3 0.25) --
+        // three passes above (and at 2^20 when the batch is too small for the two-pass pipeline).
+        if (lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
+        else if (lg <= 19) { lf[0] = 10; lf[1] = lg - 10; }
+        else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
     }
     return PATH_R2_GLOBAL;

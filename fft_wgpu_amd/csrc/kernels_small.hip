@@ -215,7 +215,7 @@ __device__ __forceinline__ void wave_transpose(v2f (&x)[16], uint32_t lane_in_gr
     });
 }
 
-template <int LGN, int DIR, bool SHFL = false>
+template <int LGN, int DIR, bool SHFL = false, bool SPLIT = (LGN >= 13)>
 __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small16(const v2f *__restrict__ src,
                                                                                   v2f *__restrict__ dst,
                                                                                   const v2f *__restrict__ tw,
@@ -261,49 +261,186 @@ __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small1
         });
         return;
     }
-    // stage 0: global -> (LDS | global)
-    {
-        constexpr bool only = (NS16 == 1 && RL == 1);
-        if (live || !only)
-            stage_bfly<16, N, DIR>([&](uint32_t i) { return live ? g_in[i] : v2f{0.f, 0.f}; },
-                                   [&](uint32_t o, v2f v) {
-                                       if constexpr (only) { if (live) g_out[o] = v * scale; }
-                                       else lds[pad(o)] = v;
-                                   },
-                                   tw, t, 1u);
-        if constexpr (only) return;
+    // Exchange between two stages: every thread deposits its 16 stage outputs v[q] at positions opos(q) and
+    // collects its 16 next-stage inputs from positions ipos(m).  SPLIT (n = 8192, 16384): real parts first, then
+    // imaginary parts, through a float buffer of half the size -- 34 / 68 KiB instead of 68 / 136 KiB, i.e. 4 / 2
+    // workgroups per CU instead of 2 / 1 (same padding: one element per 16, conflict-free for b32 as for b64).
+    auto exchange = [&](v2f (&v)[16], auto opos, v2f (&x)[16], auto ipos) {
+        if constexpr (SPLIT) {
+            float *lf = reinterpret_cast<float *>(smem) + (threadIdx.x / TPX) * PADN;
+            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lf[pad(opos(q_))] = v[q].x; });
+            __syncthreads();
+            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m].x = lf[pad(ipos(m_))]; });
+            __syncthreads();
+            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lf[pad(opos(q_))] = v[q].y; });
+            __syncthreads();
+            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m].y = lf[pad(ipos(m_))]; });
+            __syncthreads();
+        } else {
+            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(opos(q_))] = v[q]; });
+            __syncthreads();
+            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(ipos(m_))]; });
+            __syncthreads();
+        }
+    };
+    v2f v[16], x[16];
+    // stage 0 (J = 1, s = t): inputs t + m*N/16 straight from global memory, output q at t*16 + q, twiddle W_n^{t*q}
+    static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = live ? g_in[t + m * TPX] : v2f{0.f, 0.f}; });
+    fft_reg<16, DIR>(x);
+    static_for<0, 16>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        v[q] = x[brev<16>(q)];
+        if constexpr (q != 0 && N > 16) v[q] = cmul_tw<DIR>(v[q], tw_lookup<N>(tw, t * q));
+    });
+    if constexpr (NS16 == 1 && RL == 1) {  // n = 16
+        static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; if (live) g_out[t * 16 + q] = v[q] * scale; });
+        return;
     }
-    uint32_t J = 16;
+    uint32_t J = 16, jj = 0, sJ = t;  // positions of v[q]: sJ*16 + jj + q*(J/16)
     // middle radix-16 stages
     static_for<1, NS16>([&](auto s_) {
         constexpr int st = decltype(s_)::value;
         constexpr bool last = (st == NS16 - 1) && RL == 1;
-        __syncthreads();
-        v2f x[16];
-        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * (N / 16))]; });
-        if constexpr (!last) __syncthreads();
+        const uint32_t Jp = J / 16, jo = jj, so = sJ;
+        exchange(v, [&](auto q_) { return so * 16 + jo + (uint32_t)decltype(q_)::value * Jp; }, x,
+                 [&](auto m_) { return t + (uint32_t)decltype(m_)::value * (N / 16); });
         fft_reg<16, DIR>(x);
-        const uint32_t j = t & (J - 1), sJ = t - j;
+        jj = t & (J - 1);
+        sJ = t - jj;
         static_for<0, 16>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
-            v2f v = x[brev<16>(q)];
-            if constexpr (q != 0 && !last) v = cmul_tw<DIR>(v, tw_lookup<N>(tw, sJ * q));
-            const uint32_t o = sJ * 16 + j + q * J;
-            if constexpr (last) { if (live) g_out[o] = v * scale; }
-            else lds[pad(o)] = v;
+            v[q] = x[brev<16>(q)];
+            if constexpr (q != 0 && !last) v[q] = cmul_tw<DIR>(v[q], tw_lookup<N>(tw, sJ * q));
+            if constexpr (last) { if (live) g_out[sJ * 16 + jj + q * J] = v[q] * scale; }
         });
         J *= 16;
     });
-    // last stage of radix RL < 16: 16/RL butterflies per thread, outputs straight to global
+    // last stage of radix RL < 16: 16/RL butterflies per thread (idx = t + b*TPX < J, so s = 0: no twiddle),
+    // inputs idx + m*N/RL, output q straight to global memory at idx + q*J
     if constexpr (RL > 1) {
-        __syncthreads();
+        const uint32_t Jp = J / 16, jo = jj, so = sJ;
+        exchange(v, [&](auto q_) { return so * 16 + jo + (uint32_t)decltype(q_)::value * Jp; }, x,
+                 [&](auto i_) {
+                     constexpr uint32_t i = decltype(i_)::value;
+                     return t + (i / RL) * TPX + (i % RL) * (N / RL);
+                 });
         static_for<0, 16 / RL>([&](auto b_) {
             constexpr int b = decltype(b_)::value;
-            stage_bfly<RL, N, DIR>([&](uint32_t i) { return lds[pad(i)]; },
-                                   [&](uint32_t o, v2f v) { if (live) g_out[o] = v * scale; }, tw, t + b * TPX, J);
+            v2f z[RL];
+            static_for<0, RL>([&](auto m_) { constexpr int m = decltype(m_)::value; z[m] = x[b * RL + m]; });
+            fft_reg<RL, DIR>(z);
+            static_for<0, RL>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if (live) g_out[t + b * TPX + q * J] = z[brev<RL>(q)] * scale;
+            });
         });
     }
 }
+
+// ---------------------------------------------------------------------------
+// n = 8192, 16384, 32768: 32 points per thread, three register stages (32 x 16 x 16 / 32 x 32 x 16 / 32 x 32 x 32)
+// and TWO exchanges (k_small16 needs three at these sizes), each through a float buffer -- real parts, then imaginary
+// parts.  n/32 threads per transform (256 / 512 / 1024), 33 / 66 / 132 KiB of LDS: four / two / one workgroup(s) and
+// 256 KiB of loads in flight per CU (k_small16 at 8192 / 16384: 128 KiB; measured 0.37 / 0.40 -> 0.63 / 0.66 of the
+// roofline).  Same Stockham recurrence per stage, radix R: idx = s*J + j, inputs idx + m*n/R, output q at
+// s*R*J + j + q*J times W_n^{s*J*q}.  Positions are padded by one float per 32 (conflict-free b32 accesses).
+// ---------------------------------------------------------------------------
+// x[brev<R>(q)] *= W_N^{e*q} for q = 1 .. R-1 with 7 + R/8 - 1 table look-ups instead of R - 1:
+// W^{e(8a + b)} = W^{8ea} * W^{eb} (one extra rounding on the twiddles that are products, as in k_tile).
+template <int R, int N, int DIR>
+__device__ __forceinline__ void twiddle_outputs(v2f (&x)[R], const v2f *__restrict__ tw, uint32_t e)
+{
+    static_assert(R == 16 || R == 32, "radix");
+    v2f pb[8], pa[R / 8];
+    static_for<1, 8>([&](auto b_) { constexpr int b = decltype(b_)::value; pb[b] = tw_lookup<N>(tw, e * b); });
+    static_for<1, R / 8>([&](auto a_) { constexpr int a = decltype(a_)::value; pa[a] = tw_lookup<N>(tw, e * (8 * a)); });
+    static_for<1, R>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        constexpr int a = q / 8, b = q % 8, r = brev<R>(q);
+        if constexpr (a == 0) x[r] = cmul_tw<DIR>(x[r], pb[b]);
+        else if constexpr (b == 0) x[r] = cmul_tw<DIR>(x[r], pa[a]);
+        else x[r] = cmul_tw<DIR>(x[r], cmul(pa[a], pb[b]));
+    });
+}
+
+template <int LGN, int DIR>
+__global__ __launch_bounds__((1 << (LGN - 5)), 4) void k_small32(const v2f *__restrict__ src, v2f *__restrict__ dst,
+                                                              const v2f *__restrict__ tw, uint64_t batch, float scale)
+{
+    static_assert(LGN >= 13 && LGN <= 15, "k_small32 covers n = 8192, 16384, 32768");
+    constexpr int N = 1 << LGN;
+    constexpr int T = N / 32;                     // threads = butterflies of a radix-32 stage
+    constexpr int R1 = (LGN >= 14) ? 32 : 16;     // middle radix
+    constexpr int R2 = (LGN == 15) ? 32 : 16;     // last radix
+    constexpr int B1 = 32 / R1, B2 = 32 / R2;     // butterflies per thread in those stages
+    constexpr int J2 = 32 * R1;                   // = N / R2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lf = reinterpret_cast<float *>(smem);
+    const uint32_t t = threadIdx.x;
+    const v2f *g_in = src + (uint64_t)blockIdx.x * N;
+    v2f *g_out = dst + (uint64_t)blockIdx.x * N;
+
+    // In-place exchange: register r deposits its value at wbase + woff(r) and is refilled from rbase + roff(r); real
+    // parts first (x[r].y still holds the old imaginary part meanwhile), then imaginary parts.  Every position is a
+    // lane-dependent base plus a compile-time offset (P(a + b) = P(a) + P(b) for the padding P(p) = p + p/32 whenever
+    // b is a multiple of 32), so each access is one ds instruction with an immediate offset.
+    auto exchange = [&](v2f (&x)[32], uint32_t wbase, auto woff, uint32_t rbase, auto roff) {
+        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; lf[wbase + woff(r_)] = x[r].x; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r].x = lf[rbase + roff(r_)]; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; lf[wbase + woff(r_)] = x[r].y; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r].y = lf[rbase + roff(r_)]; });
+    };
+    constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
+    const uint32_t t_hi = t >> 5, t_lo = t & 31;
+    const uint32_t rbase = t + t_hi;  // P(t): reads of both exchanges start at element t plus a multiple of 32
+
+    v2f x[32];
+    // stage 0: radix 32, J = 1, s = t; output q is left in x[brev(q)]
+    // buffer (SRD) addressing: one per-lane offset, the per-access part is a scalar (no address VGPR per access)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(g_in), 0, N * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(g_out, 0, N * 8, 0x00020000);
+    static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, t * 8, m * T * 8); });
+    fft_reg<32, DIR>(x);
+    twiddle_outputs<32, N, DIR>(x, tw, t);
+    // -> stage 1 (radix R1, J = 32): butterfly b of this thread is idx = t + b*T, input m at idx + m*N/R1
+    // output q at t*32 + q -> P = 33*t + q
+    exchange(x, 33 * t, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, rbase, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P((i / R1) * T + (i % R1) * (N / R1));
+    });
+    static_for<0, B1>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
+        fft_reg<R1, DIR>(z);
+        const uint32_t idx = t + b * T, sJ = idx & ~31u;
+        twiddle_outputs<R1, N, DIR>(z, tw, sJ);  // output q: position sJ*R1 + j + q*32
+    });
+    __syncthreads();  // every read of the first exchange is done before its buffer is rewritten
+    // -> stage 2 (radix R2, J = N/R2, s = 0): butterfly b is idx = t + b*T < N/R2, input m at idx + m*N/R2
+    // output q of butterfly b at sJ*R1 + j + q*32 with sJ = (t & ~31) + b*T, j = t & 31:
+    // lane part (t & ~31)*R1 + (t & 31), padded by (t >> 5)*R1; constant part b*T*R1 + q*32
+    exchange(x, (t - t_lo) * R1 + t_lo + t_hi * R1, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P((i / R1) * T * R1 + (uint32_t)brev<R1>(i % R1) * 32);
+    }, rbase, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P((i / R2) * T + (i % R2) * (N / R2));
+    });
+    static_for<0, B2>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        v2f(&z)[R2] = *reinterpret_cast<v2f(*)[R2]>(&x[b * R2]);
+        fft_reg<R2, DIR>(z);
+        static_for<0, R2>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            buf_store<AUX_NT>(z[brev<R2>(q)] * scale, rout, t * 8, (b * T + q * J2) * 8);
+        });
+    });
+}
+
+static size_t small32_lds(uint32_t lg_n) { return ((size_t)(1u << lg_n) + (1u << (lg_n - 5))) * sizeof(float); }
 
 template <int DIR>
 static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t batch, float scale,
@@ -314,7 +451,7 @@ static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, ui
     const uint32_t xpw = wg / (n / 16);
     const uint64_t blocks = (batch + xpw - 1) / xpw;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
+    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * (lg_n >= 13 ? sizeof(float) : sizeof(v2f));
     const dim3 g((uint32_t)blocks), b(wg);
     switch (lg_n) {
         case 4: hipLaunchKernelGGL((k_small16<4, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
@@ -335,8 +472,9 @@ static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, ui
         case 10: hipLaunchKernelGGL((k_small16<10, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 11: hipLaunchKernelGGL((k_small16<11, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 12: hipLaunchKernelGGL((k_small16<12, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 13: hipLaunchKernelGGL((k_small16<13, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 14: hipLaunchKernelGGL((k_small16<14, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
+        case 13: hipLaunchKernelGGL((k_small32<13, DIR>), dim3((uint32_t)batch), dim3(256), small32_lds(13), st, src, dst, tw, batch, scale); break;
+        case 14: hipLaunchKernelGGL((k_small32<14, DIR>), dim3((uint32_t)batch), dim3(512), small32_lds(14), st, src, dst, tw, batch, scale); break;
+        case 15: hipLaunchKernelGGL((k_small32<15, DIR>), dim3((uint32_t)batch), dim3(1024), small32_lds(15), st, src, dst, tw, batch, scale); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -354,15 +492,13 @@ hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint
 
 hipError_t setup_small_kernels()
 {
-    // 8192 / 16384-point transforms need 68 / 136 KiB of dynamic LDS
-    const void *ks[4] = {reinterpret_cast<const void *>(&k_small16<13, FWD>), reinterpret_cast<const void *>(&k_small16<13, INV>),
-                         reinterpret_cast<const void *>(&k_small16<14, FWD>), reinterpret_cast<const void *>(&k_small16<14, INV>)};
-    for (int i = 0; i < 4; ++i) {
-        const int n = i < 2 ? 8192 : 16384;
-        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (n + n / 16) * 8);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    // 16384 / 32768-point transforms need 66 / 132 KiB of dynamic LDS (8192: 33 KiB, inside the default limit)
+    hipError_t e = hipSuccess;
+    const void *ks[4] = {reinterpret_cast<const void *>(&k_small32<14, FWD>), reinterpret_cast<const void *>(&k_small32<14, INV>),
+                         reinterpret_cast<const void *>(&k_small32<15, FWD>), reinterpret_cast<const void *>(&k_small32<15, INV>)};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)small32_lds(i < 2 ? 14 : 15));
+    return e;
 }
 
 

@@ -81,17 +81,17 @@ def test_path_selection_host_logic():
     """fwa_describe_path: the plan's path/factorisation logic runs without a device."""
     import fft_wgpu_amd as fw
     assert fw.describe_path(1) == (4, [])                       # identity
-    for lg in range(1, 15):
-        assert fw.describe_path(1 << lg) == (0, [1 << lg])      # one-launch small kernels up to 16384
+    for lg in range(1, 16):
+        assert fw.describe_path(1 << lg) == (0, [1 << lg])      # one-launch kernels up to 32768
     assert fw.describe_path(1 << 20) == (1, [1024, 1024])       # headline two-pass pipeline
     assert fw.describe_path(1 << 24) == (7, [256, 256, 256])    # config C5
-    for lg in list(range(15, 20)) + list(range(21, 31)):
+    for lg in list(range(16, 20)) + list(range(21, 31)):
         path, f = fw.describe_path(1 << lg)
         assert path == 7 and all(64 <= x <= 1024 for x in f)
         prod = 1
         for x in f:
             prod *= x
-        assert prod == 1 << lg and len(f) == (2 if lg <= 17 else 3)
+        assert prod == 1 << lg and len(f) == (2 if lg <= 19 else 3)
     with pytest.raises(fw.FwaError) as e:
         fw.describe_path(1000)
     assert e.value.status == 1

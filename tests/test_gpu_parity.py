@@ -278,7 +278,7 @@ def test_distance_to_reference_restatement(gpu, oracle, n, batch):
 
 
 # ---- tiled path: several groups, two chains, ragged last group, 16- and 32-wide tiles ----
-@pytest.mark.parametrize("lg,batch,cw", [(15, 7, 32), (17, 7, 32), (18, 7, 16), (19, 7, 32), (22, 5, 32), (15, 7, 16),
+@pytest.mark.parametrize("lg,batch,cw", [(16, 7, 32), (17, 7, 32), (18, 7, 16), (19, 7, 32), (22, 5, 32), (16, 7, 16),
                                          (17, 5, 16), (21, 3, 32)])
 def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
     """group = 2 with two internal streams and an odd batch: per-group slab rotation, fork/join of the chains,
@@ -290,6 +290,7 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
     r = oracle.dft_f64(x, n, -1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2, cw=cw)
     assert plan.get("path") == 7 and plan.get("group") == 2 and which == lg % 2
+    assert (plan.get("factors") >> 16 == 0) == (lg <= 19)   # two passes up to 2^19, three above
     _check(oracle, y, r, n)
     z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2, cw=cw)
     _check(oracle, z, x.astype(np.complex128), n)
@@ -299,14 +300,14 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
 
 
 def test_tiled_default_group_with_many_groups(gpu, oracle):
-    """Default geometry, batch > 2 x group: 2^15 x 1200 (group = 512 transforms per 128-MiB slab)."""
+    """Default geometry, batch > 2 x group: 2^16 x 600 (group = 256 transforms per 128-MiB slab)."""
     fw, dev, queue = gpu
-    n, batch = 1 << 15, 1200
+    n, batch = 1 << 16, 600
     x = oracle.gen_input(n, batch, first_transform=1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n)
-    assert plan.get("path") == 7 and plan.get("group") == 512 and which == 1
+    assert plan.get("path") == 7 and plan.get("group") == 256 and which == 0
     r = oracle.dft_f64(x, n, -1)
-    for t in (0, 511, 512, 1023, 1024, 1199):
+    for t in (0, 255, 256, 511, 512, 599):
         mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
         assert mx <= REL_TOL and l2 <= REL_TOL, (t, mx, l2)
 
