@@ -32,6 +32,7 @@ enum fwa_path : int64_t {
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,    // n = 1
     PATH_RING_1M = 5,     // n = 2^20: the same two passes as ONE persistent launch with a small ring (k_ring_1m)
+    PATH_TEAM = 8,        // n = 2^16 .. 2^18: both passes in one persistent launch, intermediate in one XCD's L2 (k_team)
     PATH_TILED = 7,       // n = N1*N2[*N3], each 64..1024: 2-3 k_tile passes
 };
 
@@ -116,6 +117,8 @@ struct fwa_plan {
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
     int64_t ring_slots = 12;       // transforms of intermediate kept (>= depth + 1)
     int64_t wgs = 512;             // persistent workgroups (2 per CU)
+    // L2-resident team pipeline (PATH_TEAM)
+    int64_t max_teams = 0;         // teams (= slabs) per XCD; 0 = as many as fit 3 MiB of an XCD's 4-MiB L2
 };
 
 namespace {
@@ -322,6 +325,32 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
         p->ring = pl.ring; p->ring_bytes = pl.ring_bytes;
         return FWA_OK;
     }
+    if (p->path == PATH_TEAM) {
+        uint32_t ts = 0, th = 0;
+        size_t lds = 0;
+        fwa::team_geometry(p->lg, &ts, &th, &lds);
+        const uint64_t slab = (uint64_t)p->n * sizeof(v2f);
+        if (p->max_teams <= 0) p->max_teams = (int64_t)((3ull << 20) / slab ? (3ull << 20) / slab : 1);
+        const uint64_t need_teams = (p->batch + 7) / 8;  // more teams than transforms per XCD are useless
+        if ((uint64_t)p->max_teams > need_teams && need_teams) p->max_teams = (int64_t)need_teams;
+        p->wgs = 8 * p->max_teams * (int64_t)ts;
+        Pipeline pl;
+        pl.ring_bytes = p->batch ? 8ull * (uint64_t)p->max_teams * slab : 0;
+        uint32_t *ctl = nullptr;
+        if (pl.ring_bytes) {
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
+            if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(team slabs)");
+            ++ctx->n_ring_allocs;
+            e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::team_ctl_bytes(p->lg, (uint32_t)p->max_teams));
+            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e, "hipMalloc(team control)"); }
+        }
+        Pipeline old = take_pipeline(p);
+        destroy_pipeline_objects(ctx, old, true);
+        if (p->ring_ctl) (void)hipFree(p->ring_ctl);
+        p->ring_ctl = ctl;
+        p->ring = pl.ring; p->ring_bytes = pl.ring_bytes;
+        return FWA_OK;
+    }
     if (p->path != PATH_TWOPASS_1M && p->path != PATH_TILED) return FWA_OK;
     if (group < 1) group = 1;
     if ((uint64_t)group > p->batch && p->batch) group = (int64_t)p->batch;
@@ -389,6 +418,10 @@ int32_t setup_path(fwa_plan *p)
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_1m_done = true;
     }
+    if (p->path == PATH_TEAM) {
+        hipError_t pe = fwa::prepare_team(p->lg);
+        if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
+    }
     if (p->path == PATH_TILED) {
         const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i)
@@ -400,7 +433,8 @@ int32_t setup_path(fwa_plan *p)
     }
     // tables: shared by every plan of this (length, path, factorisation) on the context
     const uint32_t sig = p->lf[0] | (p->lf[1] << 8) | (p->lf[2] << 16);
-    const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M : p->path, sig);
+    const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M
+                                              : (p->path == PATH_TEAM ? (int64_t)PATH_TILED : p->path), sig);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
         p->tb = it->second;
@@ -421,7 +455,7 @@ int32_t setup_path(fwa_plan *p)
         return build_pipeline(p, g < 1 ? 1 : g, 2);
     }
     if (p->path == PATH_TWOPASS_1M) return build_pipeline(p, 16, 2);
-    if (p->path == PATH_RING_1M) return build_pipeline(p, 0, 0);
+    if (p->path == PATH_RING_1M || p->path == PATH_TEAM) return build_pipeline(p, 0, 0);
     return FWA_OK;
 }
 
@@ -862,6 +896,8 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
         case PATH_SMALL:
             if (plan->small_reg && plan->n < 16)
                 e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
+            else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
+                e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
             else if (plan->small_reg)
                 e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
             else
@@ -896,6 +932,12 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             const uint64_t depth = (uint64_t)plan->depth < slots ? (uint64_t)plan->depth : (slots > 1 ? slots - 1 : 1);
             e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer[0], plan->ring_ctl, (uint32_t)plan->batch,
                                     (uint32_t)depth, (uint32_t)(slots > depth ? slots : depth + 1), (uint32_t)plan->wgs, scale, st);
+            break;
+        }
+        case PATH_TEAM: {
+            if (!plan->ring || !plan->ring_ctl) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no team slabs (a failed re-tune?)");
+            e = fwa::launch_team(dir, plan->lg, a, out, plan->ring, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, tb.tw_l[1], plan->ring_ctl,
+                                 (uint32_t)plan->batch, (uint32_t)plan->max_teams, (uint32_t)plan->wgs, scale, st);
             break;
         }
         case PATH_TILED: {
@@ -972,6 +1014,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;
+    else if (k == "max_teams") *value = plan->max_teams;
     else if (k == "device_error") {
         // bounded-spin timeout flag of the persistent kernel (0 in every healthy run); synchronises the device
         *value = 0;
@@ -991,7 +1034,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "launches_per_exec") {
         switch (plan->path) {
             case PATH_TWOPASS_1M: *value = 2 * ng; break;
-            case PATH_RING_1M: *value = 1; break;
+            case PATH_RING_1M: case PATH_TEAM: *value = 1; break;
             case PATH_TILED: *value = (plan->lf[2] ? 3 : 2) * ng; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
@@ -1019,6 +1062,13 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "tile_w is 16 or 32");
         plan->tile_w = value;
         return FWA_OK;
+    }
+    if (k == "max_teams" || (k == "wgs" && plan->path == PATH_TEAM)) {
+        if (plan->path != PATH_TEAM) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the team path");
+        if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (k == "wgs") { plan->wgs = value; return FWA_OK; }
+        plan->max_teams = value;
+        return build_pipeline(plan, 0, 0);
     }
     if (k == "depth" || k == "ring_slots" || k == "wgs") {
         if (plan->path != PATH_RING_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
@@ -1065,7 +1115,9 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "small_reg") {
         if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 16384");
         if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
-        plan->small_reg = value == 2 ? 2 : (value ? 1 : 0);  // 2: wavefront-shuffle exchange at n = 32/64/128
+        // 1: register kernels (default); 2: wavefront-shuffle exchange at n = 32/64/128; 3: 16-point-per-thread kernel
+        // also at n = 512 .. 4096 (A/B against the 32-point-per-thread kernel); 0: LDS radix-2 kernel
+        plan->small_reg = (value >= 0 && value <= 3) ? value : 1;
         return FWA_OK;
     }
     if (k == "path") {
@@ -1078,6 +1130,19 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             const int32_t st = setup_path(plan);
             if (st) plan->path = old;
             if (!st && value == PATH_TWOPASS_1M && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
+            return st;
+        }
+        if ((value == PATH_TEAM || value == PATH_TILED) && (plan->path == PATH_TEAM || plan->path == PATH_TILED)) {
+            if (value == PATH_TEAM && !fwa::team_supported(plan->lg))
+                return fail(ctx, FWA_ERR_UNSUPPORTED, "the team path covers n = 2^16 .. 2^18");
+            const int64_t old = plan->path;
+            uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
+            plan->path = value;
+            if (value == PATH_TEAM) { plan->lf[0] = plan->lg / 2; plan->lf[1] = plan->lg - plan->lf[0]; plan->lf[2] = 0; }
+            else (void)choose_path(plan->n, plan->batch, plan->lf);
+            const int32_t st = setup_path(plan);
+            if (st) { plan->path = old; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
+            if (!st && value == PATH_TILED && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
             return st;
         }
         if (value == PATH_R2_GLOBAL && plan->n >= 2) {

@@ -13,6 +13,9 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 // wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           bool wave_shuffle, hipStream_t st);
+// 512 <= n <= 32768: 32 points per thread, one exchange (512, 1024) or two (kernels_small.hip: k_small32); in place allowed
+hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                          hipStream_t st);
 enum { TILE_COLS = 0, TILE_ROWS_T = 1 };
 enum { ROLE_FIRST = 1, ROLE_MIDDLE = 2, ROLE_LAST = 3 };  // cache-policy role of a tiled pass
 
@@ -37,6 +40,16 @@ struct TileArgs {
 bool tile_supported(uint32_t lg_l, uint32_t cw);
 hipError_t prepare_tile(uint32_t lg_l, uint32_t cw);
 hipError_t launch_tile(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
+// k_team (kernels_tiled.hip): both passes of an n = 2^16 .. 2^18 transform in one persistent launch, intermediate kept
+// in the L2 of one XCD.  slabs = 8 * max_teams * n elements; ctl = team_ctl_bytes() bytes (zeroed per launch; ctl[1] != 0
+// afterwards = a bounded spin timed out).
+bool team_supported(uint32_t lg_n);
+void team_geometry(uint32_t lg_n, uint32_t *team_size, uint32_t *threads, size_t *lds_bytes);
+size_t team_ctl_bytes(uint32_t lg_n, uint32_t max_teams);
+hipError_t prepare_team(uint32_t lg_n);
+hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *slabs, const v2f *tw_a, const v2f *tw_lo,
+                       const v2f *tw_hi, const v2f *tw_c, uint32_t *ctl, uint32_t batch, uint32_t max_teams,
+                       uint32_t n_workgroups, float scale, hipStream_t st);
 // n = 2, 4, 8 (in place allowed)
 hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
 hipError_t setup_small_kernels();

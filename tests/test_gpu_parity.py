@@ -47,10 +47,10 @@ def _run(fw, dev, queue, kind, x, n, **tunables):
     plan = {"Forward": lambda: fw.Forward(dev, queue, src, n),
             "Inverse": lambda: fw.Inverse(dev, queue, src, n),
             "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n)}[kind]()
-    for key in ("path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "wgs", "small_reg"):  # factors before group: it resets it
+    for key in ("path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):  # factors before group: it resets it
         if tunables.get(key) is not None:
             plan.set(key, tunables[key])
-    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "wgs", "small_reg"}
+    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"}
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -94,10 +94,11 @@ def test_reference_known_answers(gpu, known_answers):
         assert which == int(np.log2(n)) % 2    # processor.rs:153-157
 
 
-# ---- K4: numpy float64 fixtures, every power of two 2..1024: register radix-16 kernel (default), LDS radix-2
-# kernel (small_reg=0), the wavefront-shuffle exchange at n = 32/64/128 (small_reg=2) and the literal
-# one-launch-per-stage recurrence (path=2) ----
-@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 2), (None, 0), (2, None)])
+# ---- K4: numpy float64 fixtures, every power of two 2..1024: register kernels (default: 16 points per thread up to
+# 256, 32 points per thread from 512), the 16-point kernel at every size (small_reg=3), LDS radix-2 kernel
+# (small_reg=0), the wavefront-shuffle exchange at n = 32/64/128 (small_reg=2) and the literal one-launch-per-stage
+# recurrence (path=2) ----
+@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 2), (None, 3), (None, 0), (2, None)])
 def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
     fw, dev, queue = gpu
     for lg in range(1, 11):
@@ -297,6 +298,30 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
     # a different geometry computes the same bits
     y2, _, _ = _run(fw, dev, queue, "Forward", x, n, group=3, streams=1, cw=cw)
     assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
+
+
+@pytest.mark.parametrize("lg,batch,max_teams", [(16, 1, None), (16, 7, None), (16, 100, None), (16, 33, 2), (17, 5, None),
+                                                (17, 40, None), (17, 9, 1), (18, 3, None), (18, 21, None)])
+def test_team_pipeline_l2_resident(gpu, oracle, lg, batch, max_teams):
+    """path 8: both passes in ONE persistent launch, workgroups teamed up per XCD, the intermediate handed over through
+    that XCD's L2 with plain stores, sc1 loads and flag barriers.  Same tile arithmetic as the per-pass launches with the
+    same factorisation: results must be bit-identical (a stale line anywhere shows up as mismatching 128-byte lines), and
+    no bounded spin may have timed out.  Runs twice back to back on the same slabs."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    f0 = lg // 2
+    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8))
+    _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
+    for rep in range(2):
+        y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=8, max_teams=max_teams)
+        assert plan.get("path") == 8 and plan.get("launches_per_exec") == 1 and which == which_ref == lg % 2
+        assert plan.get("device_error") == 0
+        bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
+        assert bad.size == 0, (lg, batch, rep, bad.size, bad[:8])
+    z, _, plan = _run(fw, dev, queue, "Inverse", ref, n, path=8, max_teams=max_teams)
+    assert plan.get("device_error") == 0
+    _check(oracle, z, x.astype(np.complex128), n)
 
 
 def test_tiled_default_group_with_many_groups(gpu, oracle):
