@@ -106,7 +106,6 @@ struct fwa_plan {
     int64_t group = 16;            // transforms per launch
     int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
-    int64_t cw = 16;               // tiled path: FFTs per workgroup (32 where the kernel supports it)
     int64_t xcd_swizzle = 1;       // XCD-aware block -> tile mapping of the pipelined paths
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
     std::vector<hipStream_t> istreams;
@@ -396,11 +395,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
     return FWA_OK;
 }
 
-// tile width of pass i of the tiled path: the plan's cw where the kernel exists for that FFT length
-uint32_t pass_cw(const fwa_plan *p, uint32_t i)
-{
-    return (p->cw == 32 && fwa::tile_supported(p->lf[i], 32)) ? 32u : 16u;
-}
+// tile width (FFTs per workgroup) of pass i of the tiled path
+uint32_t pass_cw(const fwa_plan *, uint32_t) { return 16u; }
 
 // Everything a plan needs for its path: kernel attributes (once per context), twiddle tables (shared through the
 // context's plan cache) and, on the pipelined paths, the ring + internal streams with the default geometry.
@@ -425,11 +421,10 @@ int32_t setup_path(fwa_plan *p)
     if (p->path == PATH_TILED) {
         const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i)
-            for (uint32_t cw : {16u, 32u}) {
-                if (!fwa::tile_supported(p->lf[i], cw)) continue;
-                hipError_t pe = fwa::prepare_tile(p->lf[i], cw);
-                if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
-            }
+        {
+            hipError_t pe = fwa::prepare_tile(p->lf[i], 16);
+            if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
+        }
     }
     // tables: shared by every plan of this (length, path, factorisation) on the context
     const uint32_t sig = p->lf[0] | (p->lf[1] << 8) | (p->lf[2] << 16);
@@ -1009,7 +1004,6 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "tile_w") *value = plan->tile_w;
-    else if (k == "cw") *value = plan->cw;
     else if (k == "xcd_swizzle") *value = plan->xcd_swizzle;
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
@@ -1083,12 +1077,6 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths");
         plan->xcd_swizzle = value & 3;
-        return FWA_OK;
-    }
-    if (k == "cw") {
-        if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the tiled path");
-        if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "cw is 16 or 32");
-        plan->cw = value;
         return FWA_OK;
     }
     if (k == "factors") {

@@ -181,7 +181,8 @@ hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t b
 }
 
 // ---------------------------------------------------------------------------
-// small transforms, 16 <= n <= 4096: register radix-16 Stockham.  Each thread owns 16 points; a transform
+// small transforms, 16 <= n <= 4096: register radix-16 Stockham (the default for n <= 256; from 512 on the plan uses
+// k_small32 unless small_reg = 3).  Each thread owns 16 points; a transform
 // uses n/16 threads; stages are radix 16, 16, ... and a last stage of radix n / 16^k (2, 4 or 8 -- the
 // thread then does 16/R butterflies).  Stage recurrence = the reference's (fft.wgsl:27-62) with the pair
 // (a, b) generalised to R inputs:  idx = s*J + j;  inputs idx + m*n/R;  outputs s*R*J + j + q*J, scaled
@@ -215,15 +216,15 @@ __device__ __forceinline__ void wave_transpose(v2f (&x)[16], uint32_t lane_in_gr
     });
 }
 
-template <int LGN, int DIR, bool SHFL = false, bool SPLIT = (LGN >= 13)>
-__global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small16(const v2f *__restrict__ src,
+template <int LGN, int DIR, bool SHFL = false>
+__global__ __launch_bounds__(256) void k_small16(const v2f *__restrict__ src,
                                                                                   v2f *__restrict__ dst,
                                                                                   const v2f *__restrict__ tw,
                                                                                   uint64_t batch, float scale)
 {
     constexpr int N = 1 << LGN;
     constexpr int TPX = N / 16;                       // threads per transform
-    constexpr int WG = LGN <= 12 ? 256 : TPX;         // 8192 / 16384 points: one transform per 512 / 1024 threads
+    constexpr int WG = 256;
     constexpr int XPW = WG / TPX;                     // transforms per workgroup
     constexpr int NS16 = LGN / 4;        // radix-16 stages
     constexpr int RL = 1 << (LGN % 4);   // last radix (1 = none)
@@ -262,26 +263,12 @@ __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small1
         return;
     }
     // Exchange between two stages: every thread deposits its 16 stage outputs v[q] at positions opos(q) and
-    // collects its 16 next-stage inputs from positions ipos(m).  SPLIT (n = 8192, 16384): real parts first, then
-    // imaginary parts, through a float buffer of half the size -- 34 / 68 KiB instead of 68 / 136 KiB, i.e. 4 / 2
-    // workgroups per CU instead of 2 / 1 (same padding: one element per 16, conflict-free for b32 as for b64).
+    // collects its 16 next-stage inputs from positions ipos(m).
     auto exchange = [&](v2f (&v)[16], auto opos, v2f (&x)[16], auto ipos) {
-        if constexpr (SPLIT) {
-            float *lf = reinterpret_cast<float *>(smem) + (threadIdx.x / TPX) * PADN;
-            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lf[pad(opos(q_))] = v[q].x; });
-            __syncthreads();
-            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m].x = lf[pad(ipos(m_))]; });
-            __syncthreads();
-            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lf[pad(opos(q_))] = v[q].y; });
-            __syncthreads();
-            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m].y = lf[pad(ipos(m_))]; });
-            __syncthreads();
-        } else {
-            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(opos(q_))] = v[q]; });
-            __syncthreads();
-            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(ipos(m_))]; });
-            __syncthreads();
-        }
+        static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(opos(q_))] = v[q]; });
+        __syncthreads();
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(ipos(m_))]; });
+        __syncthreads();
     };
     v2f v[16], x[16];
     // stage 0 (J = 1, s = t): inputs t + m*N/16 straight from global memory, output q at t*16 + q, twiddle W_n^{t*q}
@@ -337,158 +324,17 @@ __global__ __launch_bounds__((LGN <= 12 ? 256 : (1 << (LGN - 4)))) void k_small1
     }
 }
 
-// ---------------------------------------------------------------------------
-// n = 512 .. 32768: 32 points per thread, register stages 32 x 16 | 32 x 32 | 32 x 32 x 2 | 32 x 32 x 4 | 32 x 16 x 16 |
-// 32 x 32 x 16 | 32 x 32 x 32, i.e. ONE exchange at 512 / 1024 and TWO above (k_small16: two / three), each through a
-// float buffer -- real parts, then imaginary parts.  n/32 threads per transform, 256-thread workgroups (512 / 1024 at
-// 16384 / 32768) with 33 KiB of LDS (66 / 132 KiB): 256 KiB of loads in flight per CU (k_small16 at 8192 / 16384:
-// 128 KiB; measured 0.37 / 0.40 -> 0.63 / 0.66 of the roofline).  Same Stockham recurrence per stage, radix R: idx = s*J + j, inputs idx + m*n/R, output q at
-// s*R*J + j + q*J times W_n^{s*J*q}.  Positions are padded by one float per 32 (conflict-free b32 accesses).
-// ---------------------------------------------------------------------------
-// x[brev<R>(q)] *= W_N^{e*q} for q = 1 .. R-1 with 7 + R/8 - 1 table look-ups instead of R - 1:
-// W^{e(8a + b)} = W^{8ea} * W^{eb} (one extra rounding on the twiddles that are products, as in k_tile).
-template <int R, int N, int DIR>
-__device__ __forceinline__ void twiddle_outputs(v2f (&x)[R], const v2f *__restrict__ tw, uint32_t e)
-{
-    static_assert(R == 16 || R == 32, "radix");
-    v2f pb[8], pa[R / 8];
-    static_for<1, 8>([&](auto b_) { constexpr int b = decltype(b_)::value; pb[b] = tw_lookup<N>(tw, e * b); });
-    static_for<1, R / 8>([&](auto a_) { constexpr int a = decltype(a_)::value; pa[a] = tw_lookup<N>(tw, e * (8 * a)); });
-    static_for<1, R>([&](auto q_) {
-        constexpr int q = decltype(q_)::value;
-        constexpr int a = q / 8, b = q % 8, r = brev<R>(q);
-        if constexpr (a == 0) x[r] = cmul_tw<DIR>(x[r], pb[b]);
-        else if constexpr (b == 0) x[r] = cmul_tw<DIR>(x[r], pa[a]);
-        else x[r] = cmul_tw<DIR>(x[r], cmul(pa[a], pb[b]));
-    });
-}
-
-template <int LGN, int DIR>
-__global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_small32(const v2f *__restrict__ src,
-                                                                                    v2f *__restrict__ dst,
-                                                                                    const v2f *__restrict__ tw,
-                                                                                    uint64_t batch, float scale)
-{
-    static_assert(LGN >= 9 && LGN <= 15, "k_small32 covers n = 512 .. 32768");
-    constexpr int N = 1 << LGN;
-    constexpr int T = N / 32;                                   // threads per transform = radix-32 butterflies
-    constexpr int WG = LGN <= 13 ? 256 : T;                     // workgroup size; XPW transforms per workgroup
-    constexpr int XPW = WG / T;
-    constexpr int R1 = (LGN == 9 || LGN == 13) ? 16 : 32;       // second radix
-    constexpr bool TWO = (32 * R1 == N);                        // n = 512, 1024: two stages, one exchange
-    constexpr int R2 = TWO ? 1 : N / (32 * R1);                 // third radix: 2, 4, 16, 16, 32 for 2^11 .. 2^15
-    constexpr int B1 = 32 / R1;                                 // butterflies per thread in stages 1 and 2
-    constexpr int J2 = 32 * R1;
-    constexpr int PN = N + N / 32;                              // padded floats per transform
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t xf = threadIdx.x / T, t = threadIdx.x % T;
-    float *lf = reinterpret_cast<float *>(smem) + xf * PN;
-    // buffer (SRD) addressing: one per-lane offset, the per-access part is a scalar (no address VGPR per access); the
-    // descriptor ends with the last valid transform of the batch, so surplus lanes of a ragged last workgroup read
-    // zeros and their stores are dropped
-    const uint64_t first = (uint64_t)blockIdx.x * XPW;
-    const uint64_t left = batch - first;
-    const uint32_t valid_bytes = (uint32_t)(left < (uint64_t)XPW ? left : (uint64_t)XPW) * (N * 8u);
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + first * N), 0, valid_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + first * N, 0, valid_bytes, 0x00020000);
-    const uint32_t voff = (xf * N + t) * 8;
-
-    // In-place exchange: register r deposits its value at wbase + woff(r) and is refilled from rbase + roff(r); real
-    // parts first (x[r].y still holds the old imaginary part meanwhile), then imaginary parts.  Every position is a
-    // lane-dependent base plus a compile-time offset: for the padding P(p) = p + p/32, P(a + b) = P(a) + P(b) whenever b
-    // is a multiple of 32 or a + (b mod 32) < 32 -- so each access is one ds instruction with an immediate offset.
-    auto exchange = [&](v2f (&x)[32], uint32_t wbase, auto woff, uint32_t rbase, auto roff) {
-        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; lf[wbase + woff(r_)] = x[r].x; });
-        __syncthreads();
-        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r].x = lf[rbase + roff(r_)]; });
-        __syncthreads();
-        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; lf[wbase + woff(r_)] = x[r].y; });
-        __syncthreads();
-        static_for<0, 32>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r].y = lf[rbase + roff(r_)]; });
-    };
-    constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
-    const uint32_t t_hi = t >> 5, t_lo = t & 31;
-    const uint32_t rbase = t + t_hi;  // P(t): every read position is element t plus a constant
-
-    v2f x[32];
-    // stage 0: radix 32, J = 1, s = t; output q is left in x[brev(q)] and goes to position t*32 + q (P = 33*t + q)
-    static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, voff, m * T * 8); });
-    fft_reg<32, DIR>(x);
-    twiddle_outputs<32, N, DIR>(x, tw, t);
-    // -> stage 1 (radix R1, J = 32): butterfly b of this thread is idx = t + b*T, input m at idx + m*N/R1
-    exchange(x, 33 * t, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, rbase, [&](auto i_) {
-        constexpr uint32_t i = decltype(i_)::value;
-        return P((i / R1) * T + (i % R1) * (N / R1));
-    });
-    if constexpr (TWO) {
-        // last stage: idx = t + b*T < 32 = J, so s = 0: no twiddle, output q at idx + q*32
-        static_for<0, B1>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
-            fft_reg<R1, DIR>(z);
-            static_for<0, R1>([&](auto q_) {
-                constexpr int q = decltype(q_)::value;
-                buf_store<AUX_NT>(z[brev<R1>(q)] * scale, rout, voff, (b * T + q * 32) * 8);
-            });
-        });
-    } else {
-        static_for<0, B1>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
-            fft_reg<R1, DIR>(z);
-            const uint32_t idx = t + b * T, sJ = idx & ~31u;
-            twiddle_outputs<R1, N, DIR>(z, tw, sJ);  // output q: position sJ*R1 + j + q*32
-        });
-        __syncthreads();  // every read of the first exchange is done before its buffer is rewritten
-        // -> stage 2 (radix R2, J = N/R2, s = 0): butterfly b is idx = t + b*T < N/R2, input m at idx + m*N/R2.
-        // Output q of stage-1 butterfly b sits at sJ*R1 + j + q*32 with sJ = (t & ~31) + b*T, j = t & 31 (T is a
-        // multiple of 32 here): lane part (t & ~31)*R1 + (t & 31), padded by (t >> 5)*R1; constant part b*T*R1 + q*32
-        constexpr int B2 = 32 / R2;
-        exchange(x, (t - t_lo) * R1 + t_lo + t_hi * R1, [&](auto i_) {
-            constexpr uint32_t i = decltype(i_)::value;
-            return P((i / R1) * T * R1 + (uint32_t)brev<R1>(i % R1) * 32);
-        }, rbase, [&](auto i_) {
-            constexpr uint32_t i = decltype(i_)::value;
-            return P((i / R2) * T + (i % R2) * (N / R2));
-        });
-        static_for<0, B2>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            v2f(&z)[R2] = *reinterpret_cast<v2f(*)[R2]>(&x[b * R2]);
-            fft_reg<R2, DIR>(z);
-            static_for<0, R2>([&](auto q_) {
-                constexpr int q = decltype(q_)::value;
-                buf_store<AUX_NT>(z[brev<R2>(q)] * scale, rout, voff, (b * T + q * J2) * 8);
-            });
-        });
-    }
-}
-
-static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }
-static size_t small32_lds(uint32_t lg_n)
-{
-    return (size_t)small32_xpw(lg_n) * ((size_t)(1u << lg_n) + (1u << (lg_n - 5))) * sizeof(float);
-}
-template <int LGN, int DIR>
-static hipError_t launch_small32_n(const v2f *src, v2f *dst, const v2f *tw, uint64_t batch, float scale, hipStream_t st)
-{
-    const uint32_t xpw = small32_xpw(LGN);
-    const uint64_t blocks = (batch + xpw - 1) / xpw;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_small32<LGN, DIR>), dim3((uint32_t)blocks), dim3(LGN <= 13 ? 256 : (1 << (LGN - 5))), small32_lds(LGN), st,
-                       src, dst, tw, batch, scale);
-    return hipGetLastError();
-}
-
 template <int DIR>
 static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t batch, float scale,
                                      bool shfl, hipStream_t st)
 {
     const uint32_t n = 1u << lg_n;
-    const uint32_t wg = lg_n <= 12 ? 256 : n / 16;
+    if (lg_n < 4 || lg_n > 12) return hipErrorInvalidValue;  // n = 8192 .. 32768: k_small32 only
+    const uint32_t wg = 256;
     const uint32_t xpw = wg / (n / 16);
     const uint64_t blocks = (batch + xpw - 1) / xpw;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * (lg_n >= 13 ? sizeof(float) : sizeof(v2f));
+    const size_t lds = (lg_n == 4 || (shfl && lg_n <= 7)) ? 0 : (size_t)xpw * (n + n / 16) * sizeof(v2f);
     const dim3 g((uint32_t)blocks), b(wg);
     switch (lg_n) {
         case 4: hipLaunchKernelGGL((k_small16<4, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
@@ -509,9 +355,6 @@ static hipError_t launch_small16_dir(const v2f *src, v2f *dst, const v2f *tw, ui
         case 10: hipLaunchKernelGGL((k_small16<10, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 11: hipLaunchKernelGGL((k_small16<11, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
         case 12: hipLaunchKernelGGL((k_small16<12, DIR>), g, b, lds, st, src, dst, tw, batch, scale); break;
-        case 13: return launch_small32_n<13, DIR>(src, dst, tw, batch, scale, st);
-        case 14: return launch_small32_n<14, DIR>(src, dst, tw, batch, scale, st);
-        case 15: return launch_small32_n<15, DIR>(src, dst, tw, batch, scale, st);
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -526,35 +369,6 @@ hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint
     return dir == FWD ? launch_small16_dir<FWD>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st)
                       : launch_small16_dir<INV>(src, dst, tw, lg_n, batch, scale, wave_shuffle, st);
 }
-
-hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                          hipStream_t st)
-{
-    if (batch == 0) return hipSuccess;
-    uint32_t lg_n = 0;
-    while ((1u << lg_n) < n) ++lg_n;
-#define FWA_S32(L)                                                                               \
-    case L:                                                                                      \
-        return dir == FWD ? launch_small32_n<L, FWD>(src, dst, tw, batch, scale, st)             \
-                          : launch_small32_n<L, INV>(src, dst, tw, batch, scale, st)
-    switch (lg_n) {
-        FWA_S32(9); FWA_S32(10); FWA_S32(11); FWA_S32(12); FWA_S32(13); FWA_S32(14); FWA_S32(15);
-        default: return hipErrorInvalidValue;
-    }
-#undef FWA_S32
-}
-
-hipError_t setup_small_kernels()
-{
-    // 16384 / 32768-point transforms need 66 / 132 KiB of dynamic LDS (8192: 33 KiB, inside the default limit)
-    hipError_t e = hipSuccess;
-    const void *ks[4] = {reinterpret_cast<const void *>(&k_small32<14, FWD>), reinterpret_cast<const void *>(&k_small32<14, INV>),
-                         reinterpret_cast<const void *>(&k_small32<15, FWD>), reinterpret_cast<const void *>(&k_small32<15, INV>)};
-    for (int i = 0; i < 4 && e == hipSuccess; ++i)
-        e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)small32_lds(i < 2 ? 14 : 15));
-    return e;
-}
-
 
 // ---------------------------------------------------------------------------
 // elementwise: normalize (normalize.wgsl:9-12), synthetic fill, calibration copy

@@ -146,19 +146,25 @@ int32_t fwa_plan_destroy(fwa_plan *plan);
  * (0 = unused), e.g. 2^20 -> {10,10,0}, 2^24 -> {8,8,8}, 512 -> {9,0,0}. */
 int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors[3]);
 
-/* Introspection / tuning (no reference analogue).  No key changes what a plan computes.
+/* Introspection / tuning (no reference analogue).  No key changes what a plan computes: every path and geometry
+ * of a size produces the same transform (the tests compare them bit for bit where they share arithmetic).
  * Keys for fwa_plan_get_i64:
  *   "batch", "fft_len",
- *   "path": 0 one-launch kernels (n <= 16384), 1 two-pass 2^20 pipeline, 2 literal radix-2 recurrence (one
- *           launch per stage, kernel/fft.wgsl:27-62; forced only), 3 normalize, 4 identity (n = 1),
- *           7 tiled 2-3 pass pipeline (2^15..2^19, 2^21..2^30, and 2^20 with fewer than 4 transforms),
+ *   "path": 0 one-launch kernels (n <= 32768), 1 two-pass 2^20 pipeline (one launch per pass and group of
+ *           transforms), 2 literal radix-2 recurrence (one launch per stage, kernel/fft.wgsl:27-62; forced only),
+ *           3 normalize, 4 identity (n = 1), 5 the 2^20 pipeline as ONE persistent launch with a small ring (opt-in),
+ *           7 tiled 2-3 pass pipeline (2^16..2^19, 2^21..2^30, and 2^20 with fewer than 4 transforms),
+ *           8 both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2 (opt-in),
  *   "factors": log2(N1) | log2(N2) << 8 | log2(N3) << 16 of a multi-pass plan,
- *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's tables),
- *   "group" (transforms per launch), "streams" (internal streams the groups alternate over),
- *   "tile_w" (2^20 path: 16 or 32 columns per tile), "cw" (tiled path: 16 or 32 FFTs per workgroup),
- *   "small_reg" (n <= 16384: 1 register radix-16 kernels, 0 LDS radix-2 kernel, 2 wave-shuffle exchange).
- * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "tile_w", "cw", "factors",
- * "small_reg", "path" (value 2 only). */
+ *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's twiddle tables),
+ *   "group" (transforms per launch), "streams" (internal streams the groups alternate over)      [paths 1, 7]
+ *   "tile_w" (16 or 32 columns per tile), "xcd_swizzle" (XCD-aware block -> tile mapping, bit 0)   [paths 1, 7]
+ *   "depth", "ring_slots", "wgs" (path 5), "max_teams", "wgs" (path 8),
+ *   "small_reg" (n <= 32768: 1 register kernels -- 16 points per thread up to 256, 32 points per thread from 512;
+ *           3 the 16-point kernel up to 4096; 2 wave-shuffle exchange at 32/64/128; 0 LDS radix-2 kernel up to 4096),
+ *   "device_error" (paths 5, 8; synchronises the device; non-zero = a bounded in-kernel spin timed out).
+ * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "tile_w", "xcd_swizzle", "factors",
+ * "depth", "ring_slots", "max_teams", "wgs", "small_reg", "path" (2 anywhere; 1 <-> 5 at 2^20; 7 <-> 8 at 2^16..2^18). */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 

@@ -47,10 +47,10 @@ def _run(fw, dev, queue, kind, x, n, **tunables):
     plan = {"Forward": lambda: fw.Forward(dev, queue, src, n),
             "Inverse": lambda: fw.Inverse(dev, queue, src, n),
             "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n)}[kind]()
-    for key in ("path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):  # factors before group: it resets it
+    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):  # factors before group: it resets it
         if tunables.get(key) is not None:
             plan.set(key, tunables[key])
-    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"}
+    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"}
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -279,9 +279,8 @@ def test_distance_to_reference_restatement(gpu, oracle, n, batch):
 
 
 # ---- tiled path: several groups, two chains, ragged last group, 16- and 32-wide tiles ----
-@pytest.mark.parametrize("lg,batch,cw", [(16, 7, 32), (17, 7, 32), (18, 7, 16), (19, 7, 32), (22, 5, 32), (16, 7, 16),
-                                         (17, 5, 16), (21, 3, 32)])
-def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
+@pytest.mark.parametrize("lg,batch", [(16, 7), (17, 7), (18, 7), (19, 7), (22, 5), (21, 3)])
+def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch):
     """group = 2 with two internal streams and an odd batch: per-group slab rotation, fork/join of the chains,
     the ragged last group and in-place operation at group granularity (default plans have one group at these
     batch sizes)."""
@@ -289,14 +288,14 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch, cw):
     n = 1 << lg
     x = oracle.gen_input(n, batch, first_transform=lg)
     r = oracle.dft_f64(x, n, -1)
-    y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2, cw=cw)
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2)
     assert plan.get("path") == 7 and plan.get("group") == 2 and which == lg % 2
     assert (plan.get("factors") >> 16 == 0) == (lg <= 19)   # two passes up to 2^19, three above
     _check(oracle, y, r, n)
-    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2, cw=cw)
+    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2)
     _check(oracle, z, x.astype(np.complex128), n)
     # a different geometry computes the same bits
-    y2, _, _ = _run(fw, dev, queue, "Forward", x, n, group=3, streams=1, cw=cw)
+    y2, _, _ = _run(fw, dev, queue, "Forward", x, n, group=3, streams=1)
     assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
 
 

@@ -12,7 +12,6 @@ import fft_wgpu_amd as fw  # noqa: E402
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cw", type=int, default=0, help="tiled path: force 16- or 32-wide tiles (0 = default)")
     ap.add_argument("--lg-min", type=int, default=1)
     ap.add_argument("--lg-max", type=int, default=24)
     args = ap.parse_args()
@@ -25,8 +24,6 @@ def main():
         n = 1 << lg
         view = dev.wrap_buffer(buf.device_ptr, n * batch * 8)
         plan = fw.Forward(dev, queue, view, n)
-        if args.cw and plan.get("path") == 7:
-            plan.set("cw", args.cw)
         reps = 5 if n * batch >= (1 << 24) else 50
         times = []
         for r in range(reps + 1):
@@ -38,7 +35,7 @@ def main():
             if r:
                 times.append(a.elapsed_ms(b))
         ms = sorted(times)[len(times) // 2]
-        print(json.dumps({"lg_n": lg, "batch": batch, "path": plan.get("path"), "factors": plan.get("factors"), "cw": plan.get("cw"), "launches": plan.get("launches_per_exec"),
+        print(json.dumps({"lg_n": lg, "batch": batch, "path": plan.get("path"), "factors": plan.get("factors"), "launches": plan.get("launches_per_exec"),
                           "ms": round(ms, 4), "Gsamples_s": round(n * batch / ms / 1e6, 2),
                           "roofline_frac": round(16 * n * batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
         plan.destroy()

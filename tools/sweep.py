@@ -68,7 +68,7 @@ def main():
     for s in settings:
         plan = fw.Forward(dev, queue, buf, n)
         kv = parse_setting(s)
-        for key in ("path", "factors", "group", "streams", "tile_w", "cw", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):
+        for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):
             if key in kv:
                 plan.set(key, kv[key])
         plans.append((s, plan, []))
@@ -89,7 +89,7 @@ def main():
         ms = sorted(times)[len(times) // 2]
         print(json.dumps({"what": "fft", "lg_n": args.lg, "batch": args.batch, "setting": s or "(default)",
                           "path": plan.get("path"), "factors": plan.get("factors"), "group": plan.get("group"),
-                          "streams": plan.get("streams"), "tile_w": plan.get("tile_w"), "cw": plan.get("cw"), "xcd_swizzle": plan.get("xcd_swizzle"),
+                          "streams": plan.get("streams"), "tile_w": plan.get("tile_w"), "xcd_swizzle": plan.get("xcd_swizzle"),
                           "ms": round(ms, 4), "ms_min": round(min(times), 4), "ms_all": [round(t, 4) for t in times],
                           "Gsamples_s": round(n * args.batch / (ms * 1e-3) / 1e9, 2),
                           "roofline_frac": round(16 * n * args.batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
