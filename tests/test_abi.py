@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert L.fwa_abi_version() == 2
 
 
+def test_rust_shim_declares_exactly_the_header_symbols():
+    """rust_shim/ cannot be compiled here (no rustc): at least its `extern "C"` block must name exactly the functions
+    include/fft_wgpu_amd.h declares, and its plans must keep the reference's public signatures."""
+    ffi = open(os.path.join(ROOT, "rust_shim", "src", "ffi.rs")).read()
+    rust_names = sorted(set(re.findall(r"pub fn (fwa_[a-z0-9_]+)\(", ffi)))
+    assert rust_names == _header_functions()
+    proc = open(os.path.join(ROOT, "rust_shim", "src", "processor.rs")).read()
+    flat = re.sub(r"\s+", " ", proc)
+    for plan in ("Forward", "Inverse"):
+        assert f"impl<'a> {plan}<'a> {{ pub fn new(device: &'a wgpu::Device, queue: &'a wgpu::Queue, src: &'a wgpu::Buffer, fft_len: u32) -> Self" in flat
+    assert ("impl<'a> Onlyinverse<'a> { pub fn new( device: &'a wgpu::Device, queue: &'a wgpu::Queue, src: &'a wgpu::Buffer, "
+            "src2: &'a wgpu::Buffer, fft_len: u32, ) -> Self") in flat
+    assert ("impl<'a> Normalize<'a> { pub fn new( device: &'a wgpu::Device, queue: &'a wgpu::Queue, buffer1: &'a wgpu::Buffer, "
+            "buffer2: &'a wgpu::Buffer, fft_len: u32, ) -> Self") in flat
+    assert flat.count("pub fn proc(&self, encoder: &mut wgpu::CommandEncoder) -> &wgpu::Buffer") == 4
+    lib = open(os.path.join(ROOT, "rust_shim", "src", "lib.rs")).read()
+    assert "pub struct Complex" in lib and "pub real: f32" in lib and "pub imag: f32" in lib and "pub mod wgpu_helper;" in lib
+
+
 def test_no_device_is_an_error_not_a_fallback():
     import torch
     if torch.cuda.is_available():
