@@ -106,7 +106,8 @@ struct fwa_plan {
     int64_t group = 16;            // transforms per launch
     int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
-    int64_t xcd_swizzle = 1;       // XCD-aware block -> tile mapping of the pipelined paths
+    int64_t xcd_swizzle = -1;      // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
+                                   // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
@@ -912,13 +913,12 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             // in place at group granularity: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
             const int w = (int)plan->tile_w;
             const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
+            const uint32_t swz = plan->xcd_swizzle < 0 ? 1u : (uint32_t)plan->xcd_swizzle;
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 v2f *slab = plan->ring + (uint64_t)c * G * N;  // ring region of this chain: transform i -> slot i
-                hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt,
-                                                  (uint32_t)plan->xcd_swizzle, s);
+                hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt, swz, s);
                 if (le != hipSuccess) return le;
-                return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale,
-                                         (uint32_t)plan->xcd_swizzle, s);
+                return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale, swz, s);
             });
         }
         case PATH_RING_1M: {
@@ -945,7 +945,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 v2f *slab = plan->ring + (uint64_t)c * G * N;
                 fwa::TileArgs ta{};
-                ta.xcd_swizzle = (uint32_t)plan->xcd_swizzle;
+                ta.xcd_swizzle = plan->xcd_swizzle < 0 ? 0u : (uint32_t)plan->xcd_swizzle;
                 // pass A
                 uint32_t cw = pass_cw(plan, 0);
                 ta.in = a + g * G * N; ta.out = slab; ta.tw = tb.tw_l[0]; ta.tw_lo = tb.tw_lo1; ta.tw_hi = tb.tw_hi1;
@@ -1004,7 +1004,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "tile_w") *value = plan->tile_w;
-    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle;
+    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? 1 : 0) : plan->xcd_swizzle;
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;

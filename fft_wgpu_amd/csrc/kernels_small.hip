@@ -423,18 +423,41 @@ hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples,
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_copy(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t n_vec)
+// Calibration copy, shaped like the one-launch FFT kernels: one workgroup per contiguous 64-KiB chunk, every thread
+// issues its 16 non-temporal 16-byte loads before the first store (256 KiB in flight per CU at four workgroups).  A
+// plain grid-stride float4 copy reaches 4.7-5.0 TB/s on this part, this shape 6 TB/s and more (the 6.29 TB/s of
+// MI355X_MICROARCH.md): profiles/round2/probe_copy_shapes.txt.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy(const char *__restrict__ a, char *__restrict__ b, uint64_t n_chunks)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) b[i] = a[i];
+    constexpr uint32_t CHUNK = 65536, U = 16;
+    const uint64_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * CHUNK, 0, CHUNK, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * CHUNK, 0, CHUNK, 0x00020000);
+    v4u x[U];
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, threadIdx.x * 16, i * 4096, AUX_NT); });
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; __builtin_amdgcn_raw_buffer_store_b128(x[i], rb, threadIdx.x * 16, i * 4096, AUX_NT); });
+}
+
+__global__ __launch_bounds__(256) void k_copy_tail(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t first, uint64_t n_vec)
+{
+    const uint64_t i = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_vec) b[i] = a[i];
 }
 
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st)
 {
-    const uint64_t n_vec = bytes / 16;
+    const uint64_t n_chunks = bytes / 65536, n_vec = bytes / 16;
     if (n_vec == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_copy, dim3(stream_grid(n_vec)), dim3(256), 0, st, reinterpret_cast<const v4f *>(src),
-                       reinterpret_cast<v4f *>(dst), n_vec);
+    if (n_chunks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (n_chunks)
+        hipLaunchKernelGGL(k_copy, dim3((uint32_t)n_chunks), dim3(256), 0, st, static_cast<const char *>(src),
+                           static_cast<char *>(dst), n_chunks);
+    const uint64_t done = n_chunks * 4096;  // 16-byte vectors copied by the chunk kernel
+    if (n_vec > done)
+        hipLaunchKernelGGL(k_copy_tail, dim3((uint32_t)((n_vec - done + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const v4f *>(src), static_cast<v4f *>(dst), done, n_vec);
     return hipGetLastError();
 }
 

@@ -401,6 +401,18 @@ def test_onlyinverse_plus_normalize_equals_inverse(gpu, oracle):
         assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))             # K6, bit for bit
 
 
+def test_calibration_copy_is_a_copy(gpu, oracle):
+    """fwa_calib_copy (the measured-ceiling kernel of bench.py): chunked body + 16-byte tail, byte-exact."""
+    fw, dev, queue = gpu
+    count = (3 * 65536 + 4096 + 16) // 8          # three full 64-KiB chunks, a partial one and one last vector
+    x = oracle.gen_input(count, 1, first_transform=9)
+    a = _upload(fw, dev, queue, x)
+    b = dev.create_buffer(x.nbytes)
+    dev.calib_copy(b, a, x.nbytes)
+    dev.poll()
+    assert np.array_equal(b.map_read().view(np.uint32), x.view(np.uint32))
+
+
 def test_device_generator_is_bit_identical_to_oracle(gpu, oracle):
     fw, dev, queue = gpu
     n, batch = 4096, 9

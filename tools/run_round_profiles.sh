@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/run_round_profiles.sh -- the measurement set behind profiles/roundN (run on the GPU box through gpurun):
+# bench line, rocprofv3 kernel stats (default and single-stream), PMC fetch / write passes, size sweep, C3 variants.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final
+mkdir -p $O
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_default.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_streams1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > $O/prof_streams1.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+python3 tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch_summary.txt
+python3 tools/pmc_summary.py $O/pmc_write > $O/pmc_write_summary.txt
+python3 tools/trace_summary.py $O/prof_default > $O/trace_default_summary.txt
+python3 tools/trace_summary.py $O/prof_streams1 > $O/trace_streams1_summary.txt
+timeout -k 10 300 python3 tools/size_bench.py > $O/size_sweep.jsonl 2>&1
+timeout -k 10 300 python3 tools/sweep.py --lg 20 --batch 4096 --reps 7 --set "" --set "tile_w=32" --set "xcd_swizzle=0" --set "streams=1" --set "group=8" --set "group=32" --set "path=5" --set "path=5,depth=4,ring_slots=8" > $O/c3_variants.jsonl 2>&1
+timeout -k 10 200 python3 tools/reference_loop.py --iters 1000 > $O/reference_loop.jsonl 2>&1
+timeout -k 10 100 python3 tools/pipe_probe.py > $O/host_pipeline_probe.jsonl 2>&1
+timeout -k 10 100 python3 tools/link_probe.py > $O/host_link.jsonl 2>&1
+timeout -k 10 100 tools/copy_probe > $O/probe_copy_tuning.txt 2>&1
+echo done
