@@ -141,7 +141,7 @@ __device__ __forceinline__ bool spin_ge(uint32_t *p, uint32_t target, uint32_t *
 // exchange, store it to `dst` in the pass-2 pattern.
 template <int R, bool L2SCOPE, int hbm, int verify>
 __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox_all, const char *src, char *dst, uint32_t n_iter,
-                                                         uint32_t active_xcds)
+                                                         uint32_t active_xcds, uint32_t tokens)
 {
     constexpr int K = 32 / R;
     __shared__ uint32_t s_info[4];
@@ -173,6 +173,33 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
     uint64_t ticks = 0;
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t t = it * 8 + xcc;  // transform index
+        if (hbm == 3) {
+            // HBM token: at most `tokens` XCDs are in their HBM phase (stores of the previous transform + loads of
+            // this one) at a time, so the phases of the XCDs interleave instead of marching in step
+            if (m == 0 && tid == 0) {
+                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    if (__hip_atomic_load(&ctl->pad0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tokens) {
+                        if (__hip_atomic_fetch_add(&ctl->pad0[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tokens) break;
+                        __hip_atomic_fetch_sub(&ctl->pad0[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                    if (__builtin_amdgcn_s_memrealtime() - t0w > 20000000ull) { __hip_atomic_fetch_or(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+            __syncthreads();
+            const bool ok = flag_barrier(&ctl->flags[xcc * 64], m, barrier_no + 1, tid, &ctl->error);
+            if (tid == 0) s_info[3] = ok ? 1u : 0u;
+            __syncthreads();
+            if (!s_info[3]) return;
+            ++barrier_no;
+            if (it > 0) {  // deferred stores of the previous transform
+                auto rout = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)(t - 8) * (8u << 20), 0, 8u << 20, 0x00020000);
+                const uint32_t r2 = tid & 15, k1p = tid >> 4;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) __builtin_amdgcn_raw_buffer_store_b64(x[j], rout, (k1p * 1024 + r2) * 8, m * 128 + j * 262144, NT);
+            }
+        }
         if (hbm) {
             auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src) + (size_t)t * (8u << 20), 0, 8u << 20, 0x00020000);
             const uint32_t c = tid & 15, q = tid >> 4;
@@ -181,6 +208,16 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
         } else {
 #pragma unroll
             for (int j = 0; j < 32; ++j) x[j] = v2u{(it << 20) | (m << 12) | (uint32_t)(j << 4), tid};
+        }
+        if (hbm == 3) {  // loads landed, stores drained: hand the token back
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool ok = flag_barrier(&ctl->flags[xcc * 64], m, barrier_no + 1, tid, &ctl->error);
+            if (tid == 0) s_info[3] = ok ? 1u : 0u;
+            __syncthreads();
+            if (!s_info[3]) return;
+            ++barrier_no;
+            if (m == 0 && tid == 0) __hip_atomic_fetch_sub(&ctl->pad0[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         // ---- exchange: phase p (static register index p), partner pair-group b = (p - a) mod 32
@@ -230,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
             }
             if (bad) { atomicAdd(&ctl->mismatches, bad); __hip_atomic_fetch_or(&ctl->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
-        if (hbm) {
+        if (hbm && (hbm != 3 || it + 1 == n_iter)) {
             auto rout = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)t * (8u << 20), 0, 8u << 20, 0x00020000);
             const uint32_t r2 = tid & 15, k1p = tid >> 4;
 #pragma unroll
@@ -247,15 +284,16 @@ __global__ __launch_bounds__(512, 4) void k_xcd_exchange(Ctl *ctl, char *mailbox
 }
 
 template <int R, bool L2, int hbm>
-static void run_exchange(const char *name, Ctl *ctl, char *mailbox, char *a, char *b, uint32_t n_iter, uint32_t active = 8)
+static void run_exchange(const char *name, Ctl *ctl, char *mailbox, char *a, char *b, uint32_t n_iter, uint32_t active = 8,
+                         uint32_t tokens = 8)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f; Ctl h{};
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(ctl, 0, sizeof(Ctl)));
         CK(hipEventRecord(e0));
-        if (rep == 0 && !hbm) hipLaunchKernelGGL((k_xcd_exchange<R, L2, 0, 1>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active);
-        else hipLaunchKernelGGL((k_xcd_exchange<R, L2, hbm, 0>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active);
+        if (rep == 0 && !hbm) hipLaunchKernelGGL((k_xcd_exchange<R, L2, 0, 1>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active, tokens);
+        else hipLaunchKernelGGL((k_xcd_exchange<R, L2, hbm, 0>), dim3(512), dim3(512), 0, 0, ctl, mailbox, a, b, n_iter, active, tokens);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpy(&h, ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
@@ -327,6 +365,12 @@ int main()
         char nm[96];
         snprintf(nm, sizeof nm, "4 rounds, L2 flags, with HBM, %u active XCDs", k);
         run_exchange<4, true, 1>(nm, ctl, mailbox, a, b, 128, k);
+    }
+    printf("---- part E: HBM tokens: at most k XCDs in their HBM phase (previous stores + next loads) at a time\n");
+    for (uint32_t k : {2u, 3u, 4u, 5u, 6u, 8u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "4 rounds, L2 flags, with HBM, %u tokens", k);
+        run_exchange<4, true, 3>(nm, ctl, mailbox, a, b, 128, 8, k);
     }
     printf("budget at 70 %% of the 8 TB/s roofline: 23.4 us per transform per XCD; two-pass pipeline today: 41.6 us\n");
     return 0;
