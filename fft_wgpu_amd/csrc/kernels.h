@@ -50,7 +50,7 @@ hipError_t prepare_team(uint32_t lg_n);
 hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *slabs, const v2f *tw_a, const v2f *tw_lo,
                        const v2f *tw_hi, const v2f *tw_c, uint32_t *ctl, uint32_t batch, uint32_t max_teams,
                        uint32_t n_workgroups, float scale, hipStream_t st);
-// n = 2, 4, 8 (in place allowed)
+// n = 2, 4, 8: whole transforms per thread (in place allowed)
 hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
 hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();

@@ -122,11 +122,11 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 }
 
 // ---------------------------------------------------------------------------
-// n = 2, 4, 8: each thread owns 16 consecutive samples (16/n whole transforms), one radix-n butterfly
+// n = 4, 8: each thread owns 16 consecutive samples (16/n whole transforms), one radix-n butterfly
 // network per transform in registers, 16-byte loads and stores.
 // ---------------------------------------------------------------------------
 template <int N, int DIR>
-__global__ __launch_bounds__(256) void k_tiny(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
+__global__ __launch_bounds__(256) void k_tiny16(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
                                               float scale)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
@@ -160,18 +160,56 @@ __global__ __launch_bounds__(256) void k_tiny(const v2f *__restrict__ src, v2f *
     }
 }
 
+// ---------------------------------------------------------------------------
+// n = 2: one transform = one 16-byte load.  One workgroup per contiguous 64-KiB chunk (the shape of the calibration
+// copy), thread `tid` owns transforms u*256 + tid of the chunk (u < 16): every load and store instruction is fully
+// coalesced and all 16 loads of a thread are in flight before the first butterfly (0.51 -> 0.63 of the roofline).
+// (The same shape with one transform per thread at n >= 4 makes lanes 32+ bytes apart and runs 4-8x slower than
+// k_tiny16 / k_small16: profiles/round2/sweep_tiny_chunk_shape.jsonl.)  Buffer (SRD) addressing: the descriptor ends
+// with the data, so the last chunk needs no bounds code.
+// ---------------------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(256) void k_tiny2(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
+                                               float scale)
+{
+    constexpr uint32_t CHUNK = 65536;  // bytes per workgroup
+    const uint64_t off = (uint64_t)blockIdx.x * CHUNK;
+    const uint64_t left = n_samples * 8 - off;
+    const uint32_t valid = left < CHUNK ? (uint32_t)left : CHUNK;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(const_cast<v2f *>(src)) + off, 0, valid, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(dst) + off, 0, valid, 0x00020000);
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    v4f raw[16];
+    static_for<0, 16>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        raw[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rin, threadIdx.x * 16, u * 4096, AUX_NT));
+    });
+    static_for<0, 16>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        const v2f a = v2f{raw[u].x, raw[u].y}, b = v2f{raw[u].z, raw[u].w};
+        const v2f s = (a + b) * scale, d = (a - b) * scale;  // the 2-point DFT is direction-independent
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v4f{s.x, s.y, d.x, d.y}), rout, threadIdx.x * 16, u * 4096, AUX_NT);
+    });
+}
+
 hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st)
 {
     const uint64_t n_samples = batch * n;
     if (n_samples == 0) return hipSuccess;
+    if (n == 2) {
+        const uint64_t blocks2 = (n_samples * 8 + 65535) / 65536;
+        if (blocks2 > 0x7fffffffull) return hipErrorInvalidValue;
+        if (dir == FWD) hipLaunchKernelGGL(k_tiny2<FWD>, dim3((uint32_t)blocks2), dim3(256), 0, st, src, dst, n_samples, scale);
+        else hipLaunchKernelGGL(k_tiny2<INV>, dim3((uint32_t)blocks2), dim3(256), 0, st, src, dst, n_samples, scale);
+        return hipGetLastError();
+    }
     uint64_t blocks = (n_samples / 16 + 255) / 256 + 1;
     if (blocks > 16384) blocks = 16384;
     const dim3 g((uint32_t)blocks), b(256);
 #define FWA_TINY(NN)                                                                                        \
-    if (dir == FWD) hipLaunchKernelGGL((k_tiny<NN, FWD>), g, b, 0, st, src, dst, n_samples, scale);         \
-    else hipLaunchKernelGGL((k_tiny<NN, INV>), g, b, 0, st, src, dst, n_samples, scale)
+    if (dir == FWD) hipLaunchKernelGGL((k_tiny16<NN, FWD>), g, b, 0, st, src, dst, n_samples, scale);       \
+    else hipLaunchKernelGGL((k_tiny16<NN, INV>), g, b, 0, st, src, dst, n_samples, scale)
     switch (n) {
-        case 2: FWA_TINY(2); break;
         case 4: FWA_TINY(4); break;
         case 8: FWA_TINY(8); break;
         default: return hipErrorInvalidValue;

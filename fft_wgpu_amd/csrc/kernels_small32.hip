@@ -4,6 +4,9 @@
 namespace fwa {
 
 // ---------------------------------------------------------------------------
+// (Below 512 the same structure loses badly -- n/32 = 2 .. 8 threads per transform make every load instruction a
+// 16..64-byte-per-transform gather: 0.09 / 0.17 / 0.54 of the roofline at 64 / 128 / 256 against 0.70 for k_small16,
+// profiles/round2/sweep_small32_below_512.jsonl -- so k_small16 keeps n <= 256.)
 // n = 512 .. 32768: 32 points per thread, register stages 32 x 16 | 32 x 32 | 32 x 32 x 2 | 32 x 32 x 4 | 32 x 16 x 16 |
 // 32 x 32 x 16 | 32 x 32 x 32, i.e. ONE exchange at 512 / 1024 and TWO above (k_small16: two / three), each through a
 // float buffer -- real parts, then imaginary parts.  n/32 threads per transform, 256-thread workgroups (512 / 1024 at
@@ -41,7 +44,7 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
     constexpr int WG = LGN <= 13 ? 256 : T;                     // workgroup size; XPW transforms per workgroup
     constexpr int XPW = WG / T;
     constexpr int R1 = (LGN == 9 || LGN == 13) ? 16 : 32;       // second radix
-    constexpr bool TWO = (32 * R1 == N);                        // n = 512, 1024: two stages, one exchange
+    constexpr bool TWO = (32 * R1 == N);                        // n <= 1024: two stages, one exchange
     constexpr int R2 = TWO ? 1 : N / (32 * R1);                 // third radix: 2, 4, 16, 16, 32 for 2^11 .. 2^15
     constexpr int B1 = 32 / R1;                                 // butterflies per thread in stages 1 and 2
     constexpr int J2 = 32 * R1;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
     }
 }
 
-static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }
+static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }  // lg_n >= 6
 static size_t small32_lds(uint32_t lg_n)
 {
     return (size_t)small32_xpw(lg_n) * ((size_t)(1u << lg_n) + (1u << (lg_n - 5))) * sizeof(float);
