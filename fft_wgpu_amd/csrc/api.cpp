@@ -108,6 +108,7 @@ struct fwa_plan {
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
     int64_t xcd_swizzle = -1;      // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
                                    // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
+    int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
     int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
@@ -172,11 +173,12 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
     if (n == (1u << 20) && batch >= FEW_1M) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
-        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19 -- with a 1024-point first
-        // pass at 2^18 / 2^19 (measured: 2^18 as 1024 x 256 0.33 of the roofline, as 512 x 512 0.30, as 64^3 0.25) --
-        // three passes above (and at 2^20 when the batch is too small for the two-pass pipeline).
-        if (lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
-        else if (lg <= 19) { lf[0] = 10; lf[1] = lg - 10; }
+        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19, three above (and at 2^20 when
+        // the batch is too small for the two-pass pipeline).  A 1024-point first pass runs k_p1_gen (the 2^20
+        // pipeline's column kernel), measured faster than a balanced split wherever the other factors stay >= 64
+        // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl; 2^21 / 2^22: balanced is level or better).
+        if (lg <= 19) { lf[0] = 10; lf[1] = lg - 10; }
+        else if (lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
     }
@@ -246,6 +248,12 @@ int32_t build_tables(fwa_ctx *ctx, uint32_t n, int64_t path, const uint32_t lf[3
         const uint32_t nf = lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf && !st; ++i) st = upload_half_table(ctx, 1u << lf[i], &t->tw_l[i]);
         if (!st) st = upload_level(ctx, n, &t->tw_lo1, &t->tw_hi1);
+        if (!st && lf[0] == 10) {  // k_p1_gen's first-stage table [k1][n'] = W_1024^{n' k1}
+            std::vector<v2f> inner(1024);
+            for (uint32_t k1 = 0; k1 < 32; ++k1)
+                for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
+            st = upload_table(ctx, inner, &t->tw_inner);
+        }
         if (!st && nf == 3) st = upload_level(ctx, (uint64_t)n >> lf[0], &t->tw_lo_b, &t->tw_hi_b);
         return st;
     }
@@ -410,7 +418,7 @@ int32_t setup_path(fwa_plan *p)
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_small_done = true;
     }
-    if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M) && !ctx->setup_1m_done) {
+    if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M || (p->path == PATH_TILED && p->lf[0] == 10)) && !ctx->setup_1m_done) {
         hipError_t e = fwa::setup_1m_kernels();
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_1m_done = true;
@@ -952,7 +960,12 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.scale = 1.0f; ta.cw = cw; ta.role = fwa::ROLE_FIRST;
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
                 ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
-                hipError_t le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
+                hipError_t le;
+                if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
+                    le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
+                                            (uint32_t)cnt, ta.xcd_swizzle, s);
+                else
+                    le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
                 if (le != hipSuccess) return le;
                 if (three) {  // pass B, in place in the slab
                     cw = pass_cw(plan, 1);
@@ -1020,6 +1033,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         }
     }
     else if (k == "small_reg") *value = plan->small_reg;
+    else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
     else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
@@ -1099,6 +1113,11 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         const int32_t st = setup_path(plan);
         if (st) { plan->path = old_path; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
         return st;
+    }
+    if (k == "p1_gen") {
+        if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to tiled plans");
+        plan->p1_gen = value != 0;
+        return FWA_OK;
     }
     if (k == "small_reg") {
         if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 16384");

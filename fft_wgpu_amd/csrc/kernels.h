@@ -61,6 +61,11 @@ hipError_t launch_p1_1m(int dir, int tile_w, const v2f *src, v2f *ring, const v2
                         uint32_t n_transforms, uint32_t xcd_swizzle, hipStream_t st);
 hipError_t launch_p2_1m(int dir, int tile_w, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms,
                         float scale, uint32_t xcd_swizzle, hipStream_t st);
+// 1024-point column pass for n = 1024 * pitch (pitch = 2^4 .. 2^20 columns), matrix layout in and out, four-step
+// twiddle of domain n from the two-level table (tw_lo, tw_hi); transform i at src + i*in_sb / dst + i*out_sb.
+hipError_t launch_p1_gen(int dir, bool out_is_ring, const v2f *src, v2f *dst, const v2f *tw_inner, const v2f *tw_lo,
+                         const v2f *tw_hi, uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms,
+                         uint32_t xcd_swizzle, hipStream_t st);
 // Persistent form: one launch per exec, ring of `ring_slots` transforms (>= depth + 1); `ctl` = ring_ctl_bytes(batch)
 // bytes of device memory (zeroed here per call); ctl[1] != 0 afterwards means a bounded spin timed out.
 size_t ring_ctl_bytes(uint64_t batch);

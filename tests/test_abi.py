@@ -103,7 +103,11 @@ def test_path_selection_host_logic():
     for lg in range(1, 16):
         assert fw.describe_path(1 << lg) == (0, [1 << lg])      # one-launch kernels up to 32768
     assert fw.describe_path(1 << 20) == (1, [1024, 1024])       # headline two-pass pipeline
-    assert fw.describe_path(1 << 24) == (7, [256, 256, 256])    # config C5
+    assert fw.describe_path(1 << 24) == (7, [1024, 128, 128])   # config C5: 1024-point first pass (k_p1_gen)
+    assert fw.describe_path(1 << 16) == (7, [1024, 64])
+    assert fw.describe_path(1 << 19) == (7, [1024, 512])
+    assert fw.describe_path(1 << 22) == (7, [128, 128, 256])    # balanced: measured level with 1024 x 64 x 64
+    assert fw.describe_path(1 << 30) == (7, [1024, 1024, 1024])
     for lg in list(range(16, 20)) + list(range(21, 31)):
         path, f = fw.describe_path(1 << lg)
         assert path == 7 and all(64 <= x <= 1024 for x in f)

@@ -47,10 +47,10 @@ def _run(fw, dev, queue, kind, x, n, **tunables):
     plan = {"Forward": lambda: fw.Forward(dev, queue, src, n),
             "Inverse": lambda: fw.Inverse(dev, queue, src, n),
             "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n)}[kind]()
-    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):  # factors before group: it resets it
+    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen"):  # factors before group: it resets it
         if tunables.get(key) is not None:
             plan.set(key, tunables[key])
-    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"}
+    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen"}
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -349,6 +349,28 @@ def test_refactorised_plans_agree(gpu, oracle, lg, factors):
     _check(oracle, y, oracle.dft_f64(x, n, -1), n)
 
 
+@pytest.mark.parametrize("lg,factors,batch", [(16, (10, 6, 0), 9), (18, (10, 8, 0), 7), (19, (10, 9, 0), 3), (20, (10, 10, 0), 2),
+                                              (24, (10, 7, 7), 1), (26, (10, 8, 8), 1), (28, (10, 9, 9), 1)])
+def test_first_pass_1024_column_kernel(gpu, oracle, lg, factors, batch):
+    """Key "p1_gen": tiled plans whose first factor is 1024 run the 2^20 pipeline's column kernel at a run-time pitch
+    (k_p1_gen, twiddles of domain n computed per tile) as pass A; p1_gen = 0 runs the generic tile kernel.  Both against
+    the f64 DFT (up to 2^24) and against each other (every size; forward and inverse; ragged groups)."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    packed = factors[0] | (factors[1] << 8) | (factors[2] << 16)
+    extra = dict(group=2, streams=2) if batch > 2 else {}
+    for kind in ("Forward", "Inverse"):
+        y1, which, plan = _run(fw, dev, queue, kind, x, n, factors=packed, p1_gen=1, **extra)
+        assert plan.get("path") == 7 and plan.get("p1_gen") == 1 and which == lg % 2
+        y0, _, plan0 = _run(fw, dev, queue, kind, x, n, factors=packed, p1_gen=0, **extra)
+        assert plan0.get("p1_gen") == 0
+        mx, l2 = oracle.compare(y1, y0.astype(np.complex128))
+        assert mx <= 2e-6 and l2 <= 1e-6, (lg, kind, mx, l2)
+        if lg <= 24 and kind == "Forward":
+            _check(oracle, y1, oracle.dft_f64(x, n, -1), n)
+
+
 def test_config_c5_n16m_batch1(gpu, oracle):
     fw, dev, queue = gpu
     n = 1 << 24
@@ -577,10 +599,11 @@ def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):
     _check(oracle, y, oracle.dft_f64(x, 512, -1), 512)
 
 
-@pytest.mark.parametrize("lg", [27, 28, 29])
-def test_large_single_transform_properties(gpu, lg):
-    """n = 2^27 .. 2^29 (1 - 4 GiB per transform, three passes, 64-bit offsets inside ONE transform; at 2^29 a tile
-    spans 4 GiB and k_tile runs in its 64-bit-pointer form, BUF = false): no CPU FFT of that size in seconds, so
+@pytest.mark.parametrize("lg,p1_gen", [(27, 1), (28, 1), (29, 1), (29, 0), (30, 1)])
+def test_large_single_transform_properties(gpu, lg, p1_gen):
+    """n = 2^27 .. 2^30 (1 - 8 GiB per transform, three passes, 64-bit offsets inside ONE transform; from 2^29 a tile
+    spans >= 4 GiB: k_p1_gen addresses a transform through four descriptors, k_tile (p1_gen = 0 for pass A, always for
+    the later passes) runs in its 64-bit-pointer form, BUF = false): no CPU FFT of that size in seconds, so
     size-independent properties instead -- an impulse at p transforms to exp(-2*pi*i*p*k/n) (every output checked, in
     chunks), and forward followed by the scaled inverse restores the input to <= 1e-5."""
     fw, dev, queue = gpu
@@ -594,7 +617,8 @@ def test_large_single_transform_properties(gpu, lg):
         queue.write_buffer(src, off * 8, zeros)
     queue.write_buffer(src, p * 8, np.ones(1, dtype=np.complex64))
     plan = fw.Forward(dev, queue, src, n)
-    assert plan.get("path") == 7 and plan.get("factors") >> 16 != 0
+    plan.set("p1_gen", p1_gen)
+    assert plan.get("path") == 7 and plan.get("factors") >> 16 != 0 and plan.get("factors") & 255 == 10
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     enc.synchronize()
