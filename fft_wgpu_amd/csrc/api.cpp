@@ -109,7 +109,7 @@ struct fwa_plan {
     int64_t xcd_swizzle = -1;      // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
                                    // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
-    int64_t small_reg = 1;         // n <= 16384: 1 = register kernels, 0 = LDS radix-2 kernel, 2 = register + wave shuffles
+    int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
@@ -898,7 +898,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
             break;
         case PATH_SMALL:
-            if (plan->small_reg && plan->n < 16)
+            if (plan->small_reg == 1 && plan->n <= 256)
+                e = fwa::launch_chunk(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
+            else if (plan->small_reg && plan->n < 16)
                 e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
             else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
                 e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
@@ -1122,8 +1124,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "small_reg") {
         if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 16384");
         if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
-        // 1: register kernels (default); 2: wavefront-shuffle exchange at n = 32/64/128; 3: 16-point-per-thread kernel
-        // also at n = 512 .. 4096 (A/B against the 32-point-per-thread kernel); 0: LDS radix-2 kernel
+        // 1: k_chunk (4 .. 256) and k_small32 (from 512), the default; 3: the direct-addressing kernels k_tiny16 /
+        // k_small16 up to 4096 (A/B); 2: as 3 with the wavefront-shuffle exchange at n = 32/64/128; 0: LDS radix-2 kernel
         plan->small_reg = (value >= 0 && value <= 3) ? value : 1;
         return FWA_OK;
     }

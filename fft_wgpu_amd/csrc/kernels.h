@@ -13,6 +13,10 @@ hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, ui
 // wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           bool wave_shuffle, hipStream_t st);
+// 4 <= n <= 256: contiguous 32-KiB chunks per workgroup, linear global access, operands staged in LDS
+// (kernels_chunk.hip: k_chunk); in place allowed
+hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                        hipStream_t st);
 // 512 <= n <= 32768: 32 points per thread, one exchange (512, 1024) or two (kernels_small.hip: k_small32); in place allowed
 hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           hipStream_t st);

@@ -1,0 +1,126 @@
+// kernels_chunk.hip -- n = 4 .. 256: whole transforms inside a contiguous 32-KiB chunk per workgroup (gfx950 only).
+//
+// Below n = 512 a transform is shorter than what a wavefront moves with one instruction, so a kernel whose lanes
+// address "their" points directly (k_tiny16, k_small16) issues loads whose lanes are 16 .. 128 bytes apart: every
+// instruction touches up to 64 cache lines and the same line is touched by up to 16 instructions (0.52-0.67 of the
+// roofline).  Here global memory is only ever addressed linearly: thread `tid` of the 256 loads samples
+// u*256 + tid (u < 16) of the chunk -- 512 contiguous bytes per wavefront instruction, all 16 loads in flight before
+// the first use -- parks them in LDS (one pad element per 16: conflict-free on both sides), and the transform
+// arithmetic reads its operands from there: 16 points per thread, radix 16 [x 2, 4, 8, 16] with one exchange, as in
+// k_small16 (same recurrence, fft.wgsl:27-62 generalised to radix R; twiddle table of processor.rs:43-49).  The
+// results go back through LDS to linear stores.  The buffer descriptor ends with the data, so a ragged last chunk
+// needs no bounds code (loads return 0, stores are dropped); a chunk holds whole transforms only (n divides 4096).
+// In place allowed: a workgroup reads its chunk completely before it writes any of it.
+#include "device_common.h"
+
+namespace fwa {
+
+// T = 512 / 1024 threads per workgroup and default / sc1 policies on either side measured within noise of or slower than
+// 256 threads with nt on both sides (profiles/round2/probe_chunk_variants.txt).
+template <int LGN, int DIR, int T = 256, int AIN = AUX_NT, int AOUT = AUX_NT>
+__global__ __launch_bounds__(T) void k_chunk(const v2f *__restrict__ src, v2f *__restrict__ dst,
+                                               const v2f *__restrict__ tw, uint64_t n_samples, float scale)
+{
+    constexpr int N = 1 << LGN;
+    constexpr uint32_t CH = 16 * T;  // samples per workgroup
+    __shared__ v2f lds_all[CH + CH / 16];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e0 = (uint64_t)blockIdx.x * CH;
+    const uint64_t left = n_samples - e0;
+    const uint32_t valid = left < CH ? (uint32_t)left * 8u : CH * 8u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + e0), 0, valid, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + e0, 0, valid, 0x00020000);
+    auto pad = [](uint32_t p) { return p + (p >> 4); };
+
+    v2f x[16], v[16];
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = buf_load<AIN>(rin, tid * 8, u * T * 8); });
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_all[pad(u * T + tid)] = x[u]; });
+    __syncthreads();
+
+    if constexpr (LGN <= 4) {
+        // samples 16*tid .. 16*tid + 15 = 16/N whole transforms; the thread reads and rewrites only its own 17 slots
+        v2f *mine = lds_all + 17 * tid;
+        static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = mine[i]; });
+        static_for<0, 16 / N>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            v2f z[N];
+            static_for<0, N>([&](auto i_) { constexpr int i = decltype(i_)::value; z[i] = x[g * N + i]; });
+            fft_reg<N, DIR>(z);
+            static_for<0, N>([&](auto k_) { constexpr int k = decltype(k_)::value; mine[g * N + k] = z[brev<N>(k)] * scale; });
+        });
+    } else {
+        constexpr int TPX = N / 16;        // threads per transform
+        constexpr int RL = 1 << (LGN % 4);  // radix of the second stage when it is not 16
+        v2f *lds = lds_all + (tid / TPX) * (N + N / 16);
+        const uint32_t t = tid % TPX;
+        // stage 0 (J = 1, s = t): inputs t + m*N/16, output q at t*16 + q, twiddle W_n^{t*q}
+        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * TPX)]; });
+        fft_reg<16, DIR>(x);
+        static_for<0, 16>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            v[q] = x[brev<16>(q)];
+            if constexpr (q != 0) v[q] = cmul_tw<DIR>(v[q], tw_lookup<N>(tw, t * q));
+        });
+        __syncthreads();  // every stage-0 operand has been read
+        static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(t * 16 + q)] = v[q]; });
+        __syncthreads();
+        if constexpr (RL == 1) {  // n = 256: second radix-16 stage (s = 0, J = 16): inputs t + 16*m, output q at t + 16*q
+            static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = lds[pad(t + m * 16)]; });
+            __syncthreads();
+            fft_reg<16, DIR>(x);
+            static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(t + 16 * q)] = x[brev<16>(q)] * scale; });
+        } else {  // n = 32, 64, 128: 16/RL butterflies of radix RL (idx = t + b*TPX, s = 0), output q at idx + 16*q
+            static_for<0, 16>([&](auto i_) {
+                constexpr uint32_t i = decltype(i_)::value;
+                x[i] = lds[pad(t + (i / RL) * TPX + (i % RL) * (N / RL))];
+            });
+            __syncthreads();
+            static_for<0, 16 / RL>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                v2f z[RL];
+                static_for<0, RL>([&](auto m_) { constexpr int m = decltype(m_)::value; z[m] = x[b * RL + m]; });
+                fft_reg<RL, DIR>(z);
+                static_for<0, RL>([&](auto q_) {
+                    constexpr int q = decltype(q_)::value;
+                    lds[pad(t + b * TPX + q * 16)] = z[brev<RL>(q)] * scale;
+                });
+            });
+        }
+    }
+    __syncthreads();
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = lds_all[pad(u * T + tid)]; });
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; buf_store<AOUT>(x[u], rout, tid * 8, u * T * 8); });
+}
+
+template <int DIR>
+static hipError_t launch_chunk_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t n_samples, float scale,
+                                   hipStream_t st)
+{
+    const uint64_t blocks = (n_samples + 4095) / 4096;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 g((uint32_t)blocks), b(256);
+    switch (lg_n) {
+        case 1: hipLaunchKernelGGL((k_chunk<1, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 2: hipLaunchKernelGGL((k_chunk<2, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 3: hipLaunchKernelGGL((k_chunk<3, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 4: hipLaunchKernelGGL((k_chunk<4, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 5: hipLaunchKernelGGL((k_chunk<5, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 6: hipLaunchKernelGGL((k_chunk<6, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 7: hipLaunchKernelGGL((k_chunk<7, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        case 8: hipLaunchKernelGGL((k_chunk<8, DIR>), g, b, 0, st, src, dst, tw, n_samples, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                        hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    uint32_t lg_n = 0;
+    while ((1u << lg_n) < n) ++lg_n;
+    return dir == FWD ? launch_chunk_dir<FWD>(src, dst, tw, lg_n, batch * n, scale, st)
+                      : launch_chunk_dir<INV>(src, dst, tw, lg_n, batch * n, scale, st);
+}
+
+}  // namespace fwa

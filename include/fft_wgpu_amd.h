@@ -162,8 +162,9 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "depth", "ring_slots", "wgs" (path 5), "max_teams", "wgs" (path 8),
  *   "p1_gen" (tiled plans whose first factor is 1024: 1 = the 2^20 pipeline's column kernel at run-time
  *   pitch as pass A (default), 0 = the generic tile kernel),
- *   "small_reg" (n <= 32768: 1 register kernels -- 16 points per thread up to 256, 32 points per thread from 512;
- *           3 the 16-point kernel up to 4096; 2 wave-shuffle exchange at 32/64/128; 0 LDS radix-2 kernel up to 4096),
+ *   "small_reg" (n <= 32768: 1 = default: linear 32-KiB chunks staged through LDS for n = 4 .. 256, 32 points per
+ *           thread from 512; 3 = the direct-addressing 16-point kernels up to 4096 (A/B); 2 = wave-shuffle exchange at
+ *           32/64/128; 0 = LDS radix-2 kernel up to 4096),
  *   "device_error" (paths 5, 8; synchronises the device; non-zero = a bounded in-kernel spin timed out).
  * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "tile_w", "xcd_swizzle", "factors",
  * "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "path" (2 anywhere; 1 <-> 5 at 2^20; 7 <-> 8 at 2^16..2^18). */
