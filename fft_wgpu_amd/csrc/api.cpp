@@ -108,6 +108,7 @@ struct fwa_plan {
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
     int64_t xcd_swizzle = -1;      // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
                                    // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
+    int64_t rows32 = 1;            // two-pass tiled plans with a 512..2048-point second factor: 1 = k_rows32 as last pass
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
     int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     std::vector<hipStream_t> istreams;
@@ -173,11 +174,11 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
     if (n == (1u << 20) && batch >= FEW_1M) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
-        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19, three above (and at 2^20 when
+        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19 and at 2^21, three otherwise (and at 2^20 when
         // the batch is too small for the two-pass pipeline).  A 1024-point first pass runs k_p1_gen (the 2^20
         // pipeline's column kernel), measured faster than a balanced split wherever the other factors stay >= 64
         // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl; 2^21 / 2^22: balanced is level or better).
-        if (lg <= 19) { lf[0] = 10; lf[1] = lg - 10; }
+        if (lg <= 19 || lg == 21) { lf[0] = 10; lf[1] = lg - 10; }  // 2^21 = 1024 x 2048: rows of 2048 in k_rows32
         else if (lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
@@ -431,6 +432,11 @@ int32_t setup_path(fwa_plan *p)
         const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i)
         {
+            if (nf == 2 && i == 1 && fwa::rows32_supported(p->lf[1])) {
+                hipError_t re = fwa::prepare_rows32(p->lf[1]);
+                if (re != hipSuccess) return fail_hip(ctx, re, "hipFuncSetAttribute(max dynamic LDS)");
+            }
+            if (p->lf[i] > 10) continue;  // 2048-point rows: k_rows32 only
             hipError_t pe = fwa::prepare_tile(p->lf[i], 16);
             if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
         }
@@ -980,6 +986,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                     if (le != hipSuccess) return le;
                 }
                 // pass C: rows of the last axis, cw adjacent k1 per tile
+                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1]) && (plan->rows32 || plan->lf[1] > 10))
+                    return fwa::launch_rows32(dir, plan->lf[1], slab, out + g * G * N, tb.tw_l[1], (uint32_t)N1, N, N, (uint32_t)cnt,
+                                              scale, ta.xcd_swizzle, s);
                 const uint32_t li = three ? 2 : 1;
                 cw = pass_cw(plan, li);
                 ta.in = slab; ta.out = out + g * G * N; ta.tw = tb.tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
@@ -1036,6 +1045,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     }
     else if (k == "small_reg") *value = plan->small_reg;
     else if (k == "p1_gen") *value = plan->p1_gen;
+    else if (k == "rows32") *value = plan->rows32;
     else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
     else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
@@ -1104,7 +1114,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         const uint32_t nf = f[2] ? 3 : 2;
         uint32_t sum = 0;
         for (uint32_t i = 0; i < nf; ++i) {
-            if (f[i] < 6 || f[i] > 10) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10");
+            const uint32_t top = (nf == 2 && i == 1 && plan->lg <= 28) ? 11u : 10u;  // two passes: rows up to 2048 (k_rows32)
+            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: second of two)");
             sum += f[i];
         }
         if (sum != plan->lg || (value >> 24)) return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");
@@ -1116,9 +1127,9 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (st) { plan->path = old_path; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
         return st;
     }
-    if (k == "p1_gen") {
+    if (k == "p1_gen" || k == "rows32") {
         if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to tiled plans");
-        plan->p1_gen = value != 0;
+        (k == "p1_gen" ? plan->p1_gen : plan->rows32) = value != 0;
         return FWA_OK;
     }
     if (k == "small_reg") {

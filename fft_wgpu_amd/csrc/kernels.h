@@ -20,6 +20,12 @@ hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32
 // 512 <= n <= 32768: 32 points per thread, one exchange (512, 1024) or two (kernels_small.hip: k_small32); in place allowed
 hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           hipStream_t st);
+// last pass of a two-pass plan n = n1 * 2^lg_l (lg_l = 9 .. 11, n <= 2^28): 16 adjacent rows per workgroup, 32 points
+// per thread, transposed store out[k1 + n1*k2] (kernels_small32.hip: k_rows32); tw = half table of W_{2^lg_l}
+bool rows32_supported(uint32_t lg_l);
+hipError_t prepare_rows32(uint32_t lg_l);
+hipError_t launch_rows32(int dir, uint32_t lg_l, const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb,
+                         uint64_t out_sb, uint32_t n_transforms, float scale, uint32_t xcd_swizzle, hipStream_t st);
 enum { TILE_COLS = 0, TILE_ROWS_T = 1 };
 enum { ROLE_FIRST = 1, ROLE_MIDDLE = 2, ROLE_LAST = 3 };  // cache-policy role of a tiled pass
 

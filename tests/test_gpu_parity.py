@@ -47,10 +47,10 @@ def _run(fw, dev, queue, kind, x, n, **tunables):
     plan = {"Forward": lambda: fw.Forward(dev, queue, src, n),
             "Inverse": lambda: fw.Inverse(dev, queue, src, n),
             "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n)}[kind]()
-    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen"):  # factors before group: it resets it
+    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"):  # factors before group: it resets it
         if tunables.get(key) is not None:
             plan.set(key, tunables[key])
-    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen"}
+    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"}
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -290,7 +290,7 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch):
     r = oracle.dft_f64(x, n, -1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2)
     assert plan.get("path") == 7 and plan.get("group") == 2 and which == lg % 2
-    assert (plan.get("factors") >> 16 == 0) == (lg <= 19)   # two passes up to 2^19, three above
+    assert (plan.get("factors") >> 16 == 0) == (lg <= 19 or lg == 21)   # two passes up to 2^19 and at 2^21
     _check(oracle, y, r, n)
     z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2)
     _check(oracle, z, x.astype(np.complex128), n)
@@ -369,6 +369,31 @@ def test_first_pass_1024_column_kernel(gpu, oracle, lg, factors, batch):
         assert mx <= 2e-6 and l2 <= 1e-6, (lg, kind, mx, l2)
         if lg <= 24 and kind == "Forward":
             _check(oracle, y1, oracle.dft_f64(x, n, -1), n)
+
+
+@pytest.mark.parametrize("lg,factors,batch", [(19, (10, 9, 0), 5), (20, (10, 10, 0), 3), (21, (10, 11, 0), 3), (18, (9, 9, 0), 7),
+                                              (17, (6, 11, 0), 9), (20, (9, 11, 0), 2)])
+def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
+    """Key "rows32": two-pass tiled plans whose second factor is 512 / 1024 / 2048 run k_rows32 (32 points per thread, 16
+    adjacent rows per workgroup, last register stage in the transposed role) as their last pass; rows32 = 0 runs the
+    generic tile kernel (no 2048 there).  Forward and inverse against the f64 DFT, ragged groups and both chains."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    packed = factors[0] | (factors[1] << 8)
+    extra = dict(group=2, streams=2) if batch > 2 else {}
+    r = oracle.dft_f64(x, n, -1)
+    y1, which, plan = _run(fw, dev, queue, "Forward", x, n, factors=packed, rows32=1, **extra)
+    assert plan.get("path") == 7 and plan.get("rows32") == 1 and plan.get("launches_per_exec") == 2 * ((batch + plan.get("group") - 1) // plan.get("group"))
+    assert which == lg % 2
+    _check(oracle, y1, r, n)
+    if factors[1] <= 10:
+        y0, _, plan0 = _run(fw, dev, queue, "Forward", x, n, factors=packed, rows32=0, **extra)
+        assert plan0.get("rows32") == 0
+        mx, l2 = oracle.compare(y1, y0.astype(np.complex128))
+        assert mx <= 2e-6 and l2 <= 1e-6, (lg, mx, l2)
+    z, _, _ = _run(fw, dev, queue, "Inverse", y1, n, factors=packed, rows32=1, **extra)
+    _check(oracle, z, x.astype(np.complex128), n)
 
 
 def test_config_c5_n16m_batch1(gpu, oracle):

@@ -23,7 +23,7 @@ def main():
     enc = dev.create_command_encoder()
     plan = fw.Forward(dev, queue, buf, n)
     kv = parse_setting(args.set)
-    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg"):
+    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"):
         if key in kv:
             plan.set(key, kv[key])
     for _ in range(args.execs):

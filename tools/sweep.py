@@ -68,7 +68,7 @@ def main():
     for s in settings:
         plan = fw.Forward(dev, queue, buf, n)
         kv = parse_setting(s)
-        for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen"):
+        for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"):
             if key in kv:
                 plan.set(key, kv[key])
         plans.append((s, plan, []))
