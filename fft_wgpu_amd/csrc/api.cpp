@@ -65,7 +65,7 @@ struct fwa_ctx {
     bool setup_small_done = false;
     // plan cache: (fft_len, path, factor signature) -> tables; ring allocations of destroyed plans by size
     std::map<std::tuple<uint32_t, int64_t, uint32_t>, std::shared_ptr<Tables>> tables;
-    std::multimap<uint64_t, void *> free_rings;
+    std::vector<std::pair<uint64_t, void *>> free_rings;  // rings of destroyed plans, oldest first
     uint64_t free_ring_bytes = 0;
     int64_t n_table_builds = 0, n_table_hits = 0, n_ring_allocs = 0, n_ring_reuses = 0, last_plan_create_us = 0;
 };
@@ -163,8 +163,13 @@ uint32_t ilog2(uint32_t n)
 }
 
 // Path and per-pass FFT lengths (log2) for a transform length; shared by fwa_plan_create and fwa_describe_path.
-// `batch` matters only at n = 2^20: below FEW_1M transforms the two-pass pipeline launches too few workgroups
-// (32-64 per transform) for 256 CUs, and the three-pass tiled form (thousands of small tiles) is faster.
+// `batch` separates two regimes (profiles/round2/sweep_small_batch_latency.jsonl):
+//  * throughput (n * batch > 2^20 samples): few passes of fat tiles -- a 1024-point first pass (k_p1_gen / the 2^20
+//    pipeline, 64 KiB tiles of 512 threads) and 32-point-per-thread rows;
+//  * latency (at most 2^20 samples in flight, or a single 2^21 transform, or fewer than FEW_1M transforms of 2^20):
+//    fat tiles leave most of the 256 CUs idle (one 2^16 transform = FOUR 1024 x 16 tiles), so the plan uses the
+//    smallest tiles instead -- balanced two passes up to 2^17, balanced three passes of 64/128-point tiles above
+//    (2^16 x 1: 11.9 us against 16.2; 2^18 x 1: 12.7 against 18.4; 2^20 x 1: 19 against 24).
 constexpr uint64_t FEW_1M = 4;
 int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
 {
@@ -172,14 +177,16 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
-    if (n == (1u << 20) && batch >= FEW_1M) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
+    const bool few = (lg < 20 && batch <= ((1ull << 20) >> lg)) || (lg == 20 && batch < FEW_1M) || (lg == 21 && batch == 1);
+    if (n == (1u << 20) && !few) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
-        // factors of 64..1024 each (re-tunable: key "factors").  Two passes up to 2^19 and at 2^21, three otherwise (and at 2^20 when
-        // the batch is too small for the two-pass pipeline).  A 1024-point first pass runs k_p1_gen (the 2^20
-        // pipeline's column kernel), measured faster than a balanced split wherever the other factors stay >= 64
-        // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl; 2^21 / 2^22: balanced is level or better).
-        if (lg <= 19 || lg == 21) { lf[0] = 10; lf[1] = lg - 10; }  // 2^21 = 1024 x 2048: rows of 2048 in k_rows32
-        else if (lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
+        // factors of 64..1024 each, 2048 for the rows of a two-pass plan (re-tunable: key "factors").  Throughput
+        // regime: two passes up to 2^19 and at 2^21, three otherwise; a 1024-point first pass (k_p1_gen) wherever the
+        // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
+        // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
+        if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
+        else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
+        else if (!few && lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
     }
@@ -271,6 +278,20 @@ struct Pipeline {
     hipEvent_t fork = nullptr;
 };
 
+// newest pooled ring of exactly this size, or nullptr
+void *pool_take(fwa_ctx *ctx, uint64_t bytes)
+{
+    for (size_t i = ctx->free_rings.size(); i-- > 0;)
+        if (ctx->free_rings[i].first == bytes) {
+            void *p = ctx->free_rings[i].second;
+            ctx->free_ring_bytes -= bytes;
+            ctx->free_rings.erase(ctx->free_rings.begin() + (std::ptrdiff_t)i);
+            ++ctx->n_ring_reuses;
+            return p;
+        }
+    return nullptr;
+}
+
 void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
 {
     for (auto s : pl.streams) (void)hipStreamDestroy(s);
@@ -279,10 +300,16 @@ void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
     pl.done.clear();
     if (pl.fork) { (void)hipEventDestroy(pl.fork); pl.fork = nullptr; }
     if (pl.ring) {
-        // keep up to 1 GiB of ring allocations of destroyed plans for the next plan of the same shape
-        if (pool_ring && ctx && ctx->free_ring_bytes + pl.ring_bytes <= (1ull << 30)) {
-            ctx->free_rings.emplace(pl.ring_bytes, pl.ring);
+        // keep up to 1 GiB of ring allocations of destroyed plans for the next plan of the same shape; the oldest
+        // entries make room for newer ones
+        if (pool_ring && ctx && pl.ring_bytes <= (1ull << 30)) {
+            ctx->free_rings.emplace_back(pl.ring_bytes, pl.ring);
             ctx->free_ring_bytes += pl.ring_bytes;
+            while (ctx->free_ring_bytes > (1ull << 30)) {
+                (void)hipFree(ctx->free_rings.front().second);
+                ctx->free_ring_bytes -= ctx->free_rings.front().first;
+                ctx->free_rings.erase(ctx->free_rings.begin());
+            }
         } else {
             (void)hipFree(pl.ring);
         }
@@ -313,12 +340,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
         pl.ring_bytes = slots * (sizeof(v2f) << 20);
         uint32_t *ctl = nullptr;
         if (pl.ring_bytes) {
-            auto it = ctx->free_rings.find(pl.ring_bytes);
-            if (it != ctx->free_rings.end()) {
-                pl.ring = static_cast<v2f *>(it->second);
-                ctx->free_ring_bytes -= it->first;
-                ctx->free_rings.erase(it);
-                ++ctx->n_ring_reuses;
+            if (void *pooled = pool_take(ctx, pl.ring_bytes)) {
+                pl.ring = static_cast<v2f *>(pooled);
             } else {
                 hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
                 if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(ring)");
@@ -370,12 +393,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
     pl.ring_bytes = p->batch ? (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->n * sizeof(v2f) : 0;
     auto bail = [&](int32_t st) { destroy_pipeline_objects(ctx, pl, false); return st; };
     if (pl.ring_bytes) {
-        auto it = ctx->free_rings.find(pl.ring_bytes);
-        if (it != ctx->free_rings.end()) {
-            pl.ring = static_cast<v2f *>(it->second);
-            ctx->free_ring_bytes -= it->first;
-            ctx->free_rings.erase(it);
-            ++ctx->n_ring_reuses;
+        if (void *pooled = pool_take(ctx, pl.ring_bytes)) {
+            pl.ring = static_cast<v2f *>(pooled);
         } else {
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
             if (e != hipSuccess) { pl.ring = nullptr; return bail(fail_hip(ctx, e, "hipMalloc(ring)")); }

@@ -310,7 +310,7 @@ def test_team_pipeline_l2_resident(gpu, oracle, lg, batch, max_teams):
     n = 1 << lg
     x = oracle.gen_input(n, batch, first_transform=lg)
     f0 = lg // 2
-    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8))
+    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8), rows32=0)  # same tile arithmetic
     _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
     for rep in range(2):
         y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=8, max_teams=max_teams)
@@ -394,6 +394,22 @@ def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
         assert mx <= 2e-6 and l2 <= 1e-6, (lg, mx, l2)
     z, _, _ = _run(fw, dev, queue, "Inverse", y1, n, factors=packed, rows32=1, **extra)
     _check(oracle, z, x.astype(np.complex128), n)
+
+
+@pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (10, 6, 0)), (17, 8, (8, 9, 0)),
+                                              (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (10, 8, 0)), (19, 2, (6, 6, 7)),
+                                              (19, 3, (10, 9, 0)), (20, 3, (6, 7, 7)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
+                                              (22, 1, (7, 7, 8)), (24, 1, (10, 7, 7))])
+def test_plan_picks_small_tiles_for_few_transforms(gpu, oracle, lg, batch, factors):
+    """Latency regime (at most 2^20 samples per exec, a single 2^21, fewer than 4 of 2^20): balanced small tiles so that
+    every CU gets work; above it the 1024-point first pass.  Either way the transform is the same."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=100 + lg)
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n)
+    assert plan.get("path") == 7 and which == lg % 2
+    assert plan.get("factors") == factors[0] | (factors[1] << 8) | (factors[2] << 16)
+    _check(oracle, y, oracle.dft_f64(x, n, -1), n)
 
 
 def test_config_c5_n16m_batch1(gpu, oracle):
