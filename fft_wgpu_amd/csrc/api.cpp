@@ -187,6 +187,7 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
         if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
         else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
         else if (!few && lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
+        else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }  // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
     }

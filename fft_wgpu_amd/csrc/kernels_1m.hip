@@ -444,6 +444,7 @@ hipError_t launch_p1_gen(int dir, bool out_is_ring, const v2f *src, v2f *dst, co
     const uint64_t blocks = (uint64_t)n_transforms * (pitch / 16);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     using G = Geom<16>;
+    if (blocks % 8) xcd_swizzle = 0;  // the XCD mapping needs a grid that is a multiple of 8
     void *args[] = {&src, &dst, &tw_inner, &tw_lo, &tw_hi, &pitch, &in_sb, &out_sb, &xcd_swizzle};
     const void *k = dir == FWD ? (out_is_ring ? reinterpret_cast<const void *>(&k_p1_gen<FWD, AUX_SC1>) : reinterpret_cast<const void *>(&k_p1_gen<FWD, AUX_NT>))
                                : (out_is_ring ? reinterpret_cast<const void *>(&k_p1_gen<INV, AUX_SC1>) : reinterpret_cast<const void *>(&k_p1_gen<INV, AUX_NT>));

@@ -178,7 +178,7 @@ def test_config_c2_n1m(gpu, oracle, batch, group, streams, tile_w):
 
 def test_config_c2_n1m_batch1(gpu, oracle):
     """BASELINE config C2: one 2^20 transform.  Too few tiles for the two-pass pipeline: the plan takes the
-    three-pass tiled form (128 x 128 x 64 style factors); the result must match the pipeline's to rounding."""
+    three-pass tiled form (64 x 64 x 256); the result must match the pipeline's to rounding."""
     fw, dev, queue = gpu
     n = 1 << 20
     x = oracle.gen_input(n, 1)
@@ -398,7 +398,7 @@ def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
 
 @pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (10, 6, 0)), (17, 8, (8, 9, 0)),
                                               (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (10, 8, 0)), (19, 2, (6, 6, 7)),
-                                              (19, 3, (10, 9, 0)), (20, 3, (6, 7, 7)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
+                                              (19, 3, (10, 9, 0)), (20, 3, (6, 6, 8)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
                                               (22, 1, (7, 7, 8)), (24, 1, (10, 7, 7))])
 def test_plan_picks_small_tiles_for_few_transforms(gpu, oracle, lg, batch, factors):
     """Latency regime (at most 2^20 samples per exec, a single 2^21, fewer than 4 of 2^20): balanced small tiles so that
