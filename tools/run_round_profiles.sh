@@ -14,7 +14,7 @@ python3 tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch_summary.txt
 python3 tools/pmc_summary.py $O/pmc_write > $O/pmc_write_summary.txt
 python3 tools/trace_summary.py $O/prof_default > $O/trace_default_summary.txt
 python3 tools/trace_summary.py $O/prof_streams1 > $O/trace_streams1_summary.txt
-timeout -k 10 300 python3 tools/size_bench.py > $O/size_sweep.jsonl 2>&1
+timeout -k 10 400 python3 tools/size_bench.py --lg-max 30 > $O/size_sweep.jsonl 2>&1
 timeout -k 10 300 python3 tools/sweep.py --lg 20 --batch 4096 --reps 7 --set "" --set "tile_w=32" --set "xcd_swizzle=0" --set "streams=1" --set "group=8" --set "group=32" --set "path=5" --set "path=5,depth=4,ring_slots=8" > $O/c3_variants.jsonl 2>&1
 timeout -k 10 200 python3 tools/reference_loop.py --iters 1000 > $O/reference_loop.jsonl 2>&1
 timeout -k 10 100 python3 tools/pipe_probe.py > $O/host_pipeline_probe.jsonl 2>&1

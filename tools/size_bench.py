@@ -18,7 +18,7 @@ def main():
     dev, queue = fw.prepare_gpu(0)
     enc = dev.create_command_encoder()
     total_lg = 28
-    cases = [(lg, max(1, 1 << (total_lg - lg))) for lg in range(args.lg_min, args.lg_max + 1)] + [(20, 1), (24, 1), (10, 1)]
+    cases = [(lg, 1 << max(0, total_lg - lg)) for lg in range(args.lg_min, args.lg_max + 1)] + [(20, 1), (24, 1), (10, 1)]
     buf = dev.create_buffer(8 << max(total_lg, args.lg_max))
     for lg, batch in cases:
         n = 1 << lg
