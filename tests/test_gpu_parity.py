@@ -702,3 +702,28 @@ def test_seeded_fuzz_over_sizes_kinds_and_batches(gpu, oracle):
         for t in (0, batch // 2, batch - 1):
             mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
             assert mx <= REL_TOL and l2 <= REL_TOL, (case, lg, batch, kind, t, mx, l2)
+
+
+def test_seeded_fuzz_multipass_sizes_kinds_and_batches(gpu, oracle):
+    """30 seeded random (n = 2^16 .. 2^23, batch, kind) combinations on the default plans: both regimes (small balanced
+    tiles for few transforms, 1024-point first pass + 32-point rows otherwise), ragged groups, every kind, against the
+    fp64 DFT (all transforms)."""
+    fw, dev, queue = gpu
+    rng = np.random.default_rng(20261004)
+    seen = set()
+    for case in range(30):
+        lg = int(rng.integers(16, 24))
+        n = 1 << lg
+        batch = int(rng.integers(1, max(2, (1 << 25) >> lg) + 1))
+        kind = ("Forward", "Inverse", "Onlyinverse")[int(rng.integers(0, 3))]
+        x = oracle.gen_input(n, batch, first_transform=1000 + case)
+        y, which, plan = _run(fw, dev, queue, kind, x, n)
+        seen.add((plan.get("path"), plan.get("factors")))
+        assert which == lg % 2, (case, lg, batch, kind)
+        r = oracle.dft_f64(x, n, -1 if kind == "Forward" else +1)
+        if kind == "Inverse":
+            r = r / n
+        for t in range(batch):
+            mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
+            assert mx <= REL_TOL and l2 <= REL_TOL, (case, lg, batch, kind, t, mx, l2)
+    assert len(seen) >= 8, seen   # the draw reaches both regimes of several sizes
