@@ -727,3 +727,51 @@ def test_seeded_fuzz_multipass_sizes_kinds_and_batches(gpu, oracle):
             mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
             assert mx <= REL_TOL and l2 <= REL_TOL, (case, lg, batch, kind, t, mx, l2)
     assert len(seen) >= 8, seen   # the draw reaches both regimes of several sizes
+
+
+def test_two_contexts_interleaved_and_from_two_threads(gpu, oracle):
+    """Two contexts on the device (the C ABI's unit of isolation: own twiddle cache, ring pool, streams), used
+    interleaved from one thread and then concurrently from two host threads (one context each: the header's rule for
+    threads).  Each context's results must be those of a fresh single context."""
+    import threading
+    fw, dev, queue = gpu
+    dev2, queue2 = fw.prepare_gpu(0)
+    cases = [(1 << 12, 37, "Forward"), (1 << 20, 5, "Forward"), (1 << 17, 40, "Inverse"), (256, 1000, "Forward")]
+    want = {}
+    for n, batch, kind in cases:
+        x = oracle.gen_input(n, batch, first_transform=n % 97)
+        y, _, _ = _run(fw, dev, queue, kind, x, n)
+        want[(n, batch, kind)] = (x, y)
+    # interleaved: plan on ctx 2, plan on ctx 1, exec on 2, exec on 1
+    for n, batch, kind in cases:
+        x, y = want[(n, batch, kind)]
+        b2 = _upload(fw, dev2, queue2, x)
+        b1 = _upload(fw, dev, queue, x)
+        mk = {"Forward": fw.Forward, "Inverse": fw.Inverse}[kind]
+        p2, p1 = mk(dev2, queue2, b2, n), mk(dev, queue, b1, n)
+        e2, e1 = dev2.create_command_encoder(), dev.create_command_encoder()
+        o2 = p2.proc(e2)
+        o1 = p1.proc(e1)
+        assert np.array_equal(o2.map_read(stream=e2).view(np.uint32), y.view(np.uint32))
+        assert np.array_equal(o1.map_read(stream=e1).view(np.uint32), y.view(np.uint32))
+    assert dev2.stats()["table_builds"] >= 3 and dev2.stats()["table_cache_hits"] == 0   # its own cache
+    # two threads, one context each, 20 rounds over the cases
+    errors = []
+
+    def worker(d, q):
+        try:
+            for rnd in range(20):
+                n, batch, kind = cases[rnd % len(cases)]
+                x, y = want[(n, batch, kind)]
+                got, _, _ = _run(fw, d, q, kind, x, n)
+                if not np.array_equal(got.view(np.uint32), y.view(np.uint32)):
+                    errors.append((rnd, n, batch, kind))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(dev, queue)), threading.Thread(target=worker, args=(dev2, queue2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:4]
