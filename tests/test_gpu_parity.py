@@ -450,7 +450,9 @@ def test_impulse_tone_parseval_linearity(gpu, oracle):
 
 def test_onlyinverse_plus_normalize_equals_inverse(gpu, oracle):
     fw, dev, queue = gpu
-    for n, batch in ((512, 40), (1 << 20, 2)):
+    # one size per kernel family and plan regime, odd and even log2 n (the (a, b) rule of processor.rs:433-439)
+    for n, batch in ((8, 4000), (16, 1000), (512, 40), (1 << 13, 9), (1 << 17, 20), (1 << 19, 1), (1 << 19, 5), (1 << 20, 2),
+                     (1 << 20, 6), (1 << 21, 3), (1 << 24, 1)):
         x = oracle.gen_input(n, batch)
         src = _upload(fw, dev, queue, x)
         src2 = dev.create_buffer(x.nbytes)
