@@ -7,6 +7,9 @@ Tolerance (BASELINE.json north_star): <= 1e-5 relative fp32, measured per
 transform as max_k|y-r| / max_k|r| and rel-L2 against the fp64 DFT (SURVEY.md
 8(c)).  Integer/layout facts (result-buffer rule, generator) are bit-exact.
 """
+import ctypes
+import os
+
 import numpy as np
 import pytest
 
@@ -777,3 +780,45 @@ def test_two_contexts_interleaved_and_from_two_threads(gpu, oracle):
     for t in ts:
         t.join()
     assert not errors, errors[:4]
+
+
+def _hip_runtime():
+    """The HIP runtime the library itself is linked against (same soname -> same loaded image)."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fft_wgpu_amd", "libfft_wgpu_amd.so")
+    for line in subprocess.run(["ldd", lib], capture_output=True, text=True).stdout.splitlines():
+        if "libamdhip64" in line and "=>" in line:
+            return ctypes.CDLL(line.split("=>")[1].split()[0])
+    pytest.skip("libamdhip64 not found next to the library")
+
+
+@pytest.mark.parametrize("n,batch", [(512, 2500), (1 << 20, 40), (1 << 18, 70), (1 << 22, 3)])
+def test_exec_captures_into_a_hip_graph(gpu, oracle, n, batch):
+    """fwa_plan_exec is stream-ordered and allocates nothing, so a caller can capture it into a hipGraph (a HIP stream
+    of the caller's, wrapped with fwa_stream_wrap, captured in hipStreamCaptureModeGlobal) -- including the plans that
+    fork to internal streams and join back with events.  Replaying the graph on fresh input gives the bits of a direct
+    exec."""
+    fw, dev, queue = gpu
+    hip = _hip_runtime()
+    x = oracle.gen_input(n, batch, first_transform=n % 89)
+    ref, _, _ = _run(fw, dev, queue, "Forward", x, n)
+    src = _upload(fw, dev, queue, x)
+    plan = fw.Forward(dev, queue, src, n)
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0          # hipStreamNonBlocking
+    enc = dev.create_command_encoder(hip_stream=stream)
+    plan.proc(enc)                                                              # first-use work outside the capture
+    enc.synchronize()
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 0) == 0                            # hipStreamCaptureModeGlobal
+    out = plan.proc(enc)
+    assert hip.hipStreamEndCapture(stream, ctypes.byref(graph)) == 0
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    for rep in range(2):
+        queue.write_buffer(src, 0, x, encoder=enc)
+        assert hip.hipGraphLaunch(gexec, stream) == 0
+        y = out.map_read(stream=enc)
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (n, batch, rep)
+    assert hip.hipGraphExecDestroy(gexec) == 0 and hip.hipGraphDestroy(graph) == 0
+    del enc
+    assert hip.hipStreamDestroy(stream) == 0
