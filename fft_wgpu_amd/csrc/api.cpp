@@ -430,6 +430,15 @@ uint32_t pass_cw(const fwa_plan *, uint32_t) { return 16u; }
 
 // Everything a plan needs for its path: kernel attributes (once per context), twiddle tables (shared through the
 // context's plan cache) and, on the pipelined paths, the ring + internal streams with the default geometry.
+// Two chains (pass A of one group beside pass C of another) pay off once each chain has a few groups to run; with fewer
+// than 4 groups in all, the launches of the two chains only compete (2^20 x 32: 8.0 us per transform on two chains, 6.1
+// on one; x 64: 6.2 against 6.5; 2^18 x 128: 1.68 against 1.51; profiles/round2/sweep_mid_batch_chains.jsonl).
+int64_t default_chains(uint64_t batch, int64_t group)
+{
+    const uint64_t n_groups = group > 0 ? (batch + (uint64_t)group - 1) / (uint64_t)group : 0;
+    return n_groups >= 4 ? 2 : 1;
+}
+
 int32_t setup_path(fwa_plan *p)
 {
     fwa_ctx *ctx = p->ctx;
@@ -481,10 +490,13 @@ int32_t setup_path(fwa_plan *p)
         // the intermediate of a group of transforms lives in a ring slab of 128 MiB per chain (two chains = the
         // 256-MiB Infinity Cache; group sweep in profiles/round1/h_tiled_group_sweep.jsonl)
         const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
-        const int64_t g = (int64_t)((128ull << 20) / per);
-        return build_pipeline(p, g < 1 ? 1 : g, 2);
+        int64_t g = (int64_t)((128ull << 20) / per);
+        if (g < 1) g = 1;
+        return build_pipeline(p, g, default_chains(p->batch, g));
     }
-    if (p->path == PATH_TWOPASS_1M) return build_pipeline(p, 16, 2);
+    if (p->path == PATH_TWOPASS_1M) {
+        return build_pipeline(p, 16, default_chains(p->batch, 16));  // 16 transforms = 1024 tiles per launch
+    }
     if (p->path == PATH_RING_1M || p->path == PATH_TEAM) return build_pipeline(p, 0, 0);
     return FWA_OK;
 }

@@ -12,16 +12,17 @@ import fft_wgpu_amd as fw  # noqa: E402
 
 
 def hip_runtime():
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fft_wgpu_amd", "libfft_wgpu_amd.so")
-    for line in subprocess.run(["ldd", lib], capture_output=True, text=True).stdout.splitlines():
-        if "libamdhip64" in line and "=>" in line:
-            return ctypes.CDLL(line.split("=>")[1].split()[0])
-    raise SystemExit("libamdhip64 not found")
+    """The HIP runtime image already mapped into this process (the one the library uses)."""
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return ctypes.CDLL(line.split()[-1])
+    raise SystemExit("no libamdhip64 mapped")
 
 
 def main():
-    hip = hip_runtime()
     dev, queue = fw.prepare_gpu(0)
+    hip = hip_runtime()
     stream = ctypes.c_void_p()
     assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0
     enc = dev.create_command_encoder(hip_stream=stream)
