@@ -630,6 +630,14 @@ int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
     else if (k == "ring_allocs") *value = ctx->n_ring_allocs;
     else if (k == "ring_reuses") *value = ctx->n_ring_reuses;
     else if (k == "last_plan_create_us") *value = ctx->last_plan_create_us;
+    else if (k == "pooled_ring_bytes") *value = (int64_t)ctx->free_ring_bytes;
+    else if (k == "mem_free_bytes" || k == "mem_total_bytes") {
+        int cur = -1;
+        size_t fr = 0, tot = 0;
+        if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) (void)hipSetDevice(ctx->device);
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return fail(ctx, FWA_ERR_HIP, "hipMemGetInfo");
+        *value = (int64_t)(k == "mem_free_bytes" ? fr : tot);
+    }
     else return fail(ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
     return FWA_OK;
 }

@@ -191,7 +191,8 @@ class Device:
     def stats(self):
         """Plan-cache counters of this context (fwa_ctx_get_i64)."""
         out = {}
-        for k in ("table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "last_plan_create_us"):
+        for k in ("table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "last_plan_create_us", "pooled_ring_bytes",
+                  "mem_free_bytes", "mem_total_bytes"):
             v = ctypes.c_int64()
             _ffi.check(_ffi.lib().fwa_ctx_get_i64(self._h, k.encode(), ctypes.byref(v)), self._h, "fwa_ctx_get_i64")
             out[k] = v.value

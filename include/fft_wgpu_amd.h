@@ -75,8 +75,9 @@ int32_t fwa_ctx_destroy(fwa_ctx *ctx);
 int32_t fwa_ctx_synchronize(fwa_ctx *ctx);
 /* Context counters (no reference analogue).  Keys: "device"; plan cache (tables of a transform length are
  * built once per context and shared by every later plan of that length; ring allocations of destroyed plans
- * are reused): "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses"; "last_plan_create_us"
- * (wall time of the most recent fwa_plan_create). */
+ * are reused): "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "pooled_ring_bytes" (<= 1 GiB);
+ * "last_plan_create_us" (wall time of the most recent fwa_plan_create); "mem_free_bytes" / "mem_total_bytes"
+ * (hipMemGetInfo of the context's device). */
 int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value);
 /* name: NUL-terminated gcnArchName ("gfx950:..."), truncated to name_cap. */
 int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap,

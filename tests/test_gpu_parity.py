@@ -822,3 +822,36 @@ def test_exec_captures_into_a_hip_graph(gpu, oracle, n, batch):
     assert hip.hipGraphExecDestroy(gexec) == 0 and hip.hipGraphDestroy(graph) == 0
     del enc
     assert hip.hipStreamDestroy(stream) == 0
+
+
+def test_plan_churn_does_not_leak_device_memory(gpu, oracle):
+    """300 plans of random sizes and kinds created, run and destroyed (buffers too): afterwards the device has its memory
+    back, up to what the context keeps on purpose -- the ring pool (<= 1 GiB, reported) and the twiddle tables of the
+    lengths seen (a few MiB)."""
+    fw, dev, queue = gpu
+    rng = np.random.default_rng(7)
+    enc = dev.create_command_encoder()
+    dev.poll()
+    before = dev.stats()
+    for i in range(300):
+        lg = int(rng.integers(1, 25))
+        n = 1 << lg
+        batch = int(rng.integers(1, max(2, (1 << 25) >> lg) + 1))
+        kind = ("Forward", "Inverse", "Onlyinverse", "Normalize")[int(rng.integers(0, 4))]
+        src = dev.create_buffer(n * batch * 8)
+        src2 = dev.create_buffer(n * batch * 8) if kind in ("Onlyinverse", "Normalize") else None
+        plan = {"Forward": lambda: fw.Forward(dev, queue, src, n), "Inverse": lambda: fw.Inverse(dev, queue, src, n),
+                "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n),
+                "Normalize": lambda: fw.Normalize(dev, queue, src, src2, n)}[kind]()
+        dev.fill_synthetic(src, n, scale=1e-3, encoder=enc)
+        plan.proc(enc)
+        enc.synchronize()
+        plan.destroy()
+        src.destroy()
+        if src2 is not None:
+            src2.destroy()
+    dev.poll()
+    after = dev.stats()
+    kept = before["mem_free_bytes"] - after["mem_free_bytes"]
+    assert after["pooled_ring_bytes"] <= 1 << 30
+    assert kept <= after["pooled_ring_bytes"] - before["pooled_ring_bytes"] + (256 << 20), (kept, after)
