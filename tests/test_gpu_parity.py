@@ -613,6 +613,19 @@ def test_rejects_bad_arguments(gpu):
     assert p.get("batch") == 0
     enc = dev.create_command_encoder()
     assert p.proc(enc) is empty
+    for n in (1, 2, 16, 4096, 1 << 15, 1 << 16, 1 << 19, 1 << 20, 1 << 21, 1 << 24, 1 << 30):   # every plan family, empty
+        for mk in (fw.Forward, fw.Inverse):
+            q = mk(dev, queue, empty, n)
+            assert q.get("batch") == 0
+            q.proc(enc)
+            for key, val in (("group", 4), ("streams", 2)):
+                if q.get("path") in (1, 7):
+                    q2 = mk(dev, queue, empty, n)
+                    q2.set(key, val)
+                    q2.proc(enc)
+    enc.synchronize()
+    with pytest.raises(fw.FwaError):
+        fw.Forward(dev, queue, empty, 1 << 31)       # above 2^30
 
 
 def test_cpp_mirror_replays_reference_example(gpu, tmp_path):
