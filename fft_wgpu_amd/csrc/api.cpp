@@ -166,7 +166,7 @@ uint32_t ilog2(uint32_t n)
 // `batch` separates two regimes (profiles/round2/sweep_small_batch_latency.jsonl):
 //  * throughput (n * batch > 2^20 samples): few passes of fat tiles -- a 1024-point first pass (k_p1_gen / the 2^20
 //    pipeline, 64 KiB tiles of 512 threads) and 32-point-per-thread rows;
-//  * latency (at most 2^20 samples in flight, or a single 2^21 transform, or fewer than FEW_1M transforms of 2^20):
+//  * latency (at most 2^20 samples in flight, or a single 2^21 / 2^22 transform, or fewer than FEW_1M transforms of 2^20):
 //    fat tiles leave most of the 256 CUs idle (one 2^16 transform = FOUR 1024 x 16 tiles), so the plan uses the
 //    smallest tiles instead -- balanced two passes up to 2^17, balanced three passes of 64/128-point tiles above
 //    (2^16 x 1: 11.9 us against 16.2; 2^18 x 1: 12.7 against 18.4; 2^20 x 1: 19 against 24).
@@ -177,14 +177,15 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
-    const bool few = (lg < 20 && batch <= ((1ull << 20) >> lg)) || (lg == 20 && batch < FEW_1M) || (lg == 21 && batch == 1);
+    const bool few = (lg < 20 && batch <= ((1ull << 20) >> lg)) || (lg == 20 && batch < FEW_1M) || ((lg == 21 || lg == 22) && batch == 1);
     if (n == (1u << 20) && !few) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
         // factors of 64..1024 each, 2048 for the rows of a two-pass plan (re-tunable: key "factors").  Throughput
-        // regime: two passes up to 2^19 and at 2^21, three otherwise; a 1024-point first pass (k_p1_gen) wherever the
+        // regime: two passes up to 2^19 and at 2^21 / 2^22 (2048-point passes), three otherwise; a 1024-point first pass (k_p1_gen) wherever the
         // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
         // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
-        if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
+        if (!few && lg == 22) { lf[0] = lf[1] = 11; }  // 2048 x 2048: k_cols2048 + k_rows32
+        else if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
         else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
         else if (!few && lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }  // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
@@ -465,7 +466,11 @@ int32_t setup_path(fwa_plan *p)
                 hipError_t re = fwa::prepare_rows32(p->lf[1]);
                 if (re != hipSuccess) return fail_hip(ctx, re, "hipFuncSetAttribute(max dynamic LDS)");
             }
-            if (p->lf[i] > 10) continue;  // 2048-point rows: k_rows32 only
+            if (i == 0 && p->lf[0] == 11) {
+                hipError_t ce = fwa::prepare_cols2048();
+                if (ce != hipSuccess) return fail_hip(ctx, ce, "hipFuncSetAttribute(max dynamic LDS)");
+            }
+            if (p->lf[i] > 10) continue;  // 2048-point passes: k_cols2048 / k_rows32 only
             hipError_t pe = fwa::prepare_tile(p->lf[i], 16);
             if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
         }
@@ -1009,7 +1014,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
                 ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
                 hipError_t le;
-                if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
+                if (plan->lf[0] == 11)
+                    le = fwa::launch_cols2048(dir, true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
+                                              (uint32_t)cnt, ta.xcd_swizzle, s);
+                else if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
                     le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
                                             (uint32_t)cnt, ta.xcd_swizzle, s);
                 else
@@ -1154,8 +1162,9 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         const uint32_t nf = f[2] ? 3 : 2;
         uint32_t sum = 0;
         for (uint32_t i = 0; i < nf; ++i) {
-            const uint32_t top = (nf == 2 && i == 1 && plan->lg <= 28) ? 11u : 10u;  // two passes: rows up to 2048 (k_rows32)
-            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: second of two)");
+            // 2048: as the first factor (k_cols2048) and as the second of two (k_rows32), n <= 2^28
+            const uint32_t top = (plan->lg <= 28 && (i == 0 || (nf == 2 && i == 1))) ? 11u : 10u;
+            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: first, or second of two)");
             sum += f[i];
         }
         if (sum != plan->lg || (value >> 24)) return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");

@@ -1,0 +1,288 @@
+// kernels_rows32.hip -- the 32-point-per-thread network of k_small32 as passes of the multi-pass plans: k_rows32 (last
+// pass: 512 / 1024 / 2048-point rows with the transposed store) and k_cols2048 (first pass: 2048-point columns).
+#include "small32_common.h"
+
+namespace fwa {
+
+// ---------------------------------------------------------------------------
+// k_rows32: the LAST pass of a two-pass plan n = N1 x L with L = 512, 1024 or 2048 -- the k_small32 network on 16
+// adjacent rows (K1 = 16*tile .. +15, each a contiguous L-point transform in the slab, so the 16 rows of a tile are one
+// contiguous 16*L*8-byte chunk) with the transposed store X[K1 + N1*K2] of the four-step algorithm.  The transposition
+// costs nothing extra: the last register stage is free to pick its operands from ANY row's exchange buffer, so the
+// thread that was (row xf = tid / T, butterfly t = tid % T) while loading becomes (row r = tid % 16, butterfly
+// kk = tid / 16) for the last stage -- its outputs K2 then sit beside those of the 15 other rows of the same K2 and a
+// store instruction writes 128-byte segments.  Row buffers are skewed to 17 mod 32 floats so that the 16 rows read
+// by one instruction fall on different banks.  16*T threads (256 / 512 / 1024), 34 / 69 / 137 KiB of LDS.
+// (k_tile covers these lengths with 16 points per thread and two full-complex exchanges: 512-point rows were the slow
+// pass of the 2^19 plan, and 2048-point rows did not exist: 2^21 needed three passes.)
+// ---------------------------------------------------------------------------
+template <int LGN>
+struct Rows32 {
+    static constexpr int N = 1 << LGN, T = N / 32, WG = 16 * T;
+    static constexpr int PN = N + N / 32;
+    static constexpr int PNS = PN + ((17 - PN % 32) + 32) % 32;  // padded floats per row, = 17 mod 32
+    static constexpr int LDS_BYTES = 16 * PNS * 4;
+};
+
+template <int LGN, int DIR>
+__global__ __launch_bounds__((16 << (LGN - 5)), 4) void k_rows32(const v2f *__restrict__ in, v2f *__restrict__ out,
+                                                                  const v2f *__restrict__ tw, uint32_t n1, uint64_t in_sb,
+                                                                  uint64_t out_sb, float scale, uint32_t xcd_swizzle)
+{
+    static_assert(LGN >= 9 && LGN <= 11, "k_rows32 covers row lengths 512 .. 2048");
+    using G = Rows32<LGN>;
+    constexpr int N = G::N, T = G::T, PNS = G::PNS;
+    constexpr int R1 = (LGN == 9) ? 16 : 32;
+    constexpr bool TWO = (32 * R1 == N);
+    constexpr int R2 = TWO ? 1 : N / (32 * R1);
+    constexpr int B1 = 32 / R1;
+    constexpr int J2 = 32 * R1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x;
+    const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
+    const uint32_t tiles = n1 >> 4;
+    const uint32_t tile = bid % tiles;
+    const uint64_t bt = bid / tiles;
+    const uint32_t xf = tid / T, t = tid % T;  // loading role: row, butterfly
+    const uint32_t r = tid & 15, kk = tid >> 4;  // storing role
+    float *lfw = lds + xf * PNS;
+    const float *lfr_same = lfw;
+    const float *lfr_t = lds + r * PNS;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in + bt * in_sb + (uint64_t)tile * 16 * N), 0, 16u * N * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + bt * out_sb, 0, n1 * (N * 8u), 0x00020000);
+    const uint32_t voff = (xf * N + t) * 8;
+
+    auto exchange = [&](v2f (&x)[32], float *wp, uint32_t wbase, auto woff, const float *rp, uint32_t rbase, auto roff) {
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; wp[wbase + woff(r_)] = x[i].x; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; x[i].x = rp[rbase + roff(r_)]; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; wp[wbase + woff(r_)] = x[i].y; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; x[i].y = rp[rbase + roff(r_)]; });
+    };
+    constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
+    const uint32_t t_hi = t >> 5, t_lo = t & 31;
+
+    v2f x[32];
+    static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_DEFAULT>(rin, voff, m * T * 8); });
+    fft_reg<32, DIR>(x);
+    twiddle_outputs<32, N, DIR>(x, tw, t);
+    // transposed store role: output K2 of row r goes to element (16*tile + r) + n1*K2
+    const uint32_t voff_o = (kk * n1 + r) * 8;
+    const uint32_t soff_o = tile * 128;
+    const uint32_t kstep = n1 * 8;  // bytes per unit of K2
+    if constexpr (TWO) {
+        // -> last stage (radix R1, J = 32, s = 0) in the storing role: butterfly idx = kk + b*T of row r
+        exchange(x, lfw, 33 * t, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, lfr_t, kk + (kk >> 5), [&](auto i_) {
+            constexpr uint32_t i = decltype(i_)::value;
+            return P((i / R1) * T + (i % R1) * (N / R1));
+        });
+        static_for<0, B1>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
+            fft_reg<R1, DIR>(z);
+            static_for<0, R1>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                buf_store<AUX_NT>(z[brev<R1>(q)] * scale, rout, voff_o, soff_o + (b * T + q * 32) * kstep);
+            });
+        });
+    } else {
+        exchange(x, lfw, 33 * t, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, lfr_same, t + t_hi, [&](auto i_) {
+            constexpr uint32_t i = decltype(i_)::value;
+            return P((i / R1) * T + (i % R1) * (N / R1));
+        });
+        static_for<0, B1>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
+            fft_reg<R1, DIR>(z);
+            const uint32_t idx = t + b * T, sJ = idx & ~31u;
+            twiddle_outputs<R1, N, DIR>(z, tw, sJ);
+        });
+        __syncthreads();
+        // -> last stage (radix R2, J = N/R2, s = 0) in the storing role: butterfly idx = kk + b*T of row r
+        constexpr int B2 = 32 / R2;
+        exchange(x, lfw, (t - t_lo) * R1 + t_lo + t_hi * R1, [&](auto i_) {
+            constexpr uint32_t i = decltype(i_)::value;
+            return P((i / R1) * T * R1 + (uint32_t)brev<R1>(i % R1) * 32);
+        }, lfr_t, kk + (kk >> 5), [&](auto i_) {
+            constexpr uint32_t i = decltype(i_)::value;
+            return P((i / R2) * T + (i % R2) * (N / R2));
+        });
+        static_for<0, B2>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            v2f(&z)[R2] = *reinterpret_cast<v2f(*)[R2]>(&x[b * R2]);
+            fft_reg<R2, DIR>(z);
+            static_for<0, R2>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                buf_store<AUX_NT>(z[brev<R2>(q)] * scale, rout, voff_o, soff_o + (b * T + q * J2) * kstep);
+            });
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_cols2048: pass A of a plan whose first factor is 2048 (2^22 = 2048 x 2048 in two passes): the k_small32 network
+// (32 x 32 x 2) on 16 adjacent COLUMNS of a 2048-row matrix at run-time pitch -- the "row r = tid % 16, butterfly
+// kk = tid / 16" role of k_rows32 for every stage, so each load / store instruction moves 128-byte row segments.
+// Output in the matrix layout, multiplied by the four-step factor W_n^{col*k1} = A[kk][c] * B[j][c] (k1 = kk + off_j),
+// both from the two-level table of domain n as in k_p1_gen.  1024 threads, 137 + 4 KiB of LDS, one workgroup per CU.
+// ---------------------------------------------------------------------------
+template <int DIR, int AUX_OUT>
+__global__ __launch_bounds__(1024, 4) void k_cols2048(const v2f *__restrict__ in, v2f *__restrict__ out,
+                                                      const v2f *__restrict__ tw, const v2f *__restrict__ tw_lo,
+                                                      const v2f *__restrict__ tw_hi, uint32_t pitch, uint64_t in_sb,
+                                                      uint64_t out_sb, uint32_t xcd_swizzle)
+{
+    using G = Rows32<11>;
+    constexpr int N = G::N, T = G::T, PNS = G::PNS, J2 = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    v2f *two = reinterpret_cast<v2f *>(smem + G::LDS_BYTES);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x;
+    const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
+    const uint32_t tiles = pitch >> 4;
+    const uint32_t tile = bid % tiles;
+    const uint64_t bt = bid / tiles;
+    const uint32_t c = tid & 15, kk = tid >> 4;  // column of the tile, butterfly (0 .. 63)
+    float *lf = lds + c * PNS;
+    const uint32_t tbytes = pitch * (N * 8u);  // n * 8 <= 2^31 (launcher)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in + bt * in_sb), 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + bt * out_sb, 0, tbytes, 0x00020000);
+    const uint32_t voff = (kk * pitch + c) * 8;
+    const uint32_t soff = tile * 128;
+    const uint32_t rstep = pitch * 8;  // bytes per matrix row
+
+    v2f x[32];
+    static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, voff, soff + (m * T) * rstep); });
+    const uint32_t col = tile * 16 + c;
+    auto look = [&](uint32_t e) { return cmul(tw_hi[e >> 10], tw_lo[e & 1023]); };  // e < n
+    if (kk < 32) {  // B[j][c] = W_n^{col * off_j}, off_j = (j & 15) * 64 + (j >> 4) * 1024
+        const uint32_t off = (kk & 15) * T + (kk >> 4) * J2;
+        two[kk * 16 + c] = look(col * off);
+    }
+    const v2f A = look(col * kk);
+
+    auto exchange = [&](v2f (&v)[32], uint32_t wbase, auto woff, uint32_t rbase, auto roff) {
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; lf[wbase + woff(r_)] = v[i].x; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; v[i].x = lf[rbase + roff(r_)]; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; lf[wbase + woff(r_)] = v[i].y; });
+        __syncthreads();
+        static_for<0, 32>([&](auto r_) { constexpr int i = decltype(r_)::value; v[i].y = lf[rbase + roff(r_)]; });
+    };
+    constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
+    const uint32_t k_hi = kk >> 5, k_lo = kk & 31;
+    const uint32_t rbase = kk + k_hi;
+
+    fft_reg<32, DIR>(x);
+    twiddle_outputs<32, N, DIR>(x, tw, kk);
+    exchange(x, 33 * kk, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, rbase, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P(i * (N / 32));
+    });
+    fft_reg<32, DIR>(x);
+    twiddle_outputs<32, N, DIR>(x, tw, kk & ~31u);
+    __syncthreads();
+    exchange(x, (kk - k_lo) * 32 + k_lo + k_hi * 32, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P((uint32_t)brev<32>(i) * 32);
+    }, rbase, [&](auto i_) {
+        constexpr uint32_t i = decltype(i_)::value;
+        return P((i / 2) * T + (i % 2) * (N / 2));
+    });
+    static_for<0, 16>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        v2f(&z)[2] = *reinterpret_cast<v2f(*)[2]>(&x[b * 2]);
+        fft_reg<2, DIR>(z);
+        static_for<0, 2>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const v2f w = cmul(A, two[(q * 16 + b) * 16 + c]);
+            buf_store<AUX_OUT>(cmul_tw<DIR>(z[brev<2>(q)], w), rout, voff, soff + (b * T + q * J2) * rstep);
+        });
+    });
+}
+
+static int cols2048_lds() { return Rows32<11>::LDS_BYTES + 32 * 16 * 8; }
+static const void *cols2048_kernel(int dir, bool ring)
+{
+    return dir == FWD ? (ring ? reinterpret_cast<const void *>(&k_cols2048<FWD, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols2048<FWD, AUX_NT>))
+                      : (ring ? reinterpret_cast<const void *>(&k_cols2048<INV, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols2048<INV, AUX_NT>));
+}
+
+hipError_t prepare_cols2048()
+{
+    hipError_t e = hipSuccess;
+    for (int dir : {FWD, INV})
+        for (bool ring : {true, false})
+            if (e == hipSuccess) e = hipFuncSetAttribute(cols2048_kernel(dir, ring), hipFuncAttributeMaxDynamicSharedMemorySize, cols2048_lds());
+    return e;
+}
+
+// n = 2048 * pitch <= 2^28 per transform; tw = half table of W_2048, (tw_lo, tw_hi) = two-level table of W_n
+hipError_t launch_cols2048(int dir, bool out_is_ring, const v2f *in, v2f *out, const v2f *tw, const v2f *tw_lo, const v2f *tw_hi,
+                           uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms, uint32_t xcd_swizzle,
+                           hipStream_t st)
+{
+    if (n_transforms == 0) return hipSuccess;
+    if (pitch < 16 || pitch > (1u << 17) || (pitch & (pitch - 1))) return hipErrorInvalidValue;
+    const uint64_t blocks = (uint64_t)n_transforms * (pitch / 16);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (blocks % 8) xcd_swizzle = 0;
+    void *args[] = {&in, &out, &tw, &tw_lo, &tw_hi, &pitch, &in_sb, &out_sb, &xcd_swizzle};
+    return hipLaunchKernel(cols2048_kernel(dir, out_is_ring), dim3((uint32_t)blocks), dim3(1024), args, cols2048_lds(), st);
+}
+
+bool rows32_supported(uint32_t lg_l) { return lg_l >= 9 && lg_l <= 11; }
+
+template <int LGN, int DIR>
+static hipError_t launch_rows32_n(const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb, uint64_t out_sb,
+                                  uint32_t n_transforms, float scale, uint32_t swz, hipStream_t st)
+{
+    using G = Rows32<LGN>;
+    const uint64_t blocks = (uint64_t)n_transforms * (n1 / 16);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (blocks % 8) swz = 0;
+    hipLaunchKernelGGL((k_rows32<LGN, DIR>), dim3((uint32_t)blocks), dim3(G::WG), G::LDS_BYTES, st, in, out, tw, n1, in_sb,
+                       out_sb, scale, swz);
+    return hipGetLastError();
+}
+
+// > 64 KiB of dynamic LDS needs the attribute once per device (plan setup)
+hipError_t prepare_rows32(uint32_t lg_l)
+{
+    hipError_t e = hipSuccess;
+    auto set = [&](const void *k, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    switch (lg_l) {
+        case 9: set(reinterpret_cast<const void *>(&k_rows32<9, FWD>), Rows32<9>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<9, INV>), Rows32<9>::LDS_BYTES); break;
+        case 10: set(reinterpret_cast<const void *>(&k_rows32<10, FWD>), Rows32<10>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<10, INV>), Rows32<10>::LDS_BYTES); break;
+        case 11: set(reinterpret_cast<const void *>(&k_rows32<11, FWD>), Rows32<11>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<11, INV>), Rows32<11>::LDS_BYTES); break;
+        default: return hipErrorInvalidValue;
+    }
+    return e;
+}
+
+// n = n1 * 2^lg_l per transform, n * 8 < 2^32; `in`: n1 rows of 2^lg_l contiguous samples; out[k1 + n1*k2]
+hipError_t launch_rows32(int dir, uint32_t lg_l, const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb,
+                         uint64_t out_sb, uint32_t n_transforms, float scale, uint32_t xcd_swizzle, hipStream_t st)
+{
+    if (n_transforms == 0) return hipSuccess;
+    if (!rows32_supported(lg_l) || n1 < 16 || (n1 & (n1 - 1)) || ((uint64_t)n1 << lg_l) > (1ull << 28))
+        return hipErrorInvalidValue;
+#define FWA_R32(L)                                                                                                      \
+    case L:                                                                                                             \
+        return dir == FWD ? launch_rows32_n<L, FWD>(in, out, tw, n1, in_sb, out_sb, n_transforms, scale, xcd_swizzle, st) \
+                          : launch_rows32_n<L, INV>(in, out, tw, n1, in_sb, out_sb, n_transforms, scale, xcd_swizzle, st)
+    switch (lg_l) {
+        FWA_R32(9); FWA_R32(10); FWA_R32(11);
+        default: return hipErrorInvalidValue;
+    }
+#undef FWA_R32
+}
+
+}  // namespace fwa

@@ -154,7 +154,7 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "path": 0 one-launch kernels (n <= 32768), 1 two-pass 2^20 pipeline (one launch per pass and group of
  *           transforms), 2 literal radix-2 recurrence (one launch per stage, kernel/fft.wgsl:27-62; forced only),
  *           3 normalize, 4 identity (n = 1), 5 the 2^20 pipeline as ONE persistent launch with a small ring (opt-in),
- *           7 tiled pipeline: two passes at 2^16..2^19 and 2^21, three at 2^22..2^30 and at 2^20 with fewer than 4 transforms,
+ *           7 tiled pipeline: two passes at 2^16..2^19, 2^21 and 2^22, three at 2^23..2^30 and at 2^20 with fewer than 4 transforms,
  *           8 both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2 (opt-in),
  *   "factors": log2(N1) | log2(N2) << 8 | log2(N3) << 16 of a multi-pass plan,
  *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's twiddle tables),

@@ -293,7 +293,7 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch):
     r = oracle.dft_f64(x, n, -1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2)
     assert plan.get("path") == 7 and plan.get("group") == 2 and which == lg % 2
-    assert (plan.get("factors") >> 16 == 0) == (lg <= 19 or lg == 21)   # two passes up to 2^19 and at 2^21
+    assert (plan.get("factors") >> 16 == 0) == (lg <= 19 or lg in (21, 22))   # two passes up to 2^19 and at 2^21, 2^22
     _check(oracle, y, r, n)
     z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2)
     _check(oracle, z, x.astype(np.complex128), n)
@@ -374,6 +374,29 @@ def test_first_pass_1024_column_kernel(gpu, oracle, lg, factors, batch):
             _check(oracle, y1, oracle.dft_f64(x, n, -1), n)
 
 
+@pytest.mark.parametrize("lg,factors,batch", [(22, (11, 11, 0), 3), (21, (11, 10, 0), 2), (17, (11, 6, 0), 9), (24, (11, 6, 7), 1),
+                                              (28, (11, 8, 9), 1)])
+def test_first_pass_2048_column_kernel(gpu, oracle, lg, factors, batch):
+    """k_cols2048: pass A of plans whose first factor is 2048 (the default at 2^22 = 2048 x 2048; any other
+    factorisation through the "factors" key), forward and inverse, ragged groups, against the f64 DFT up to 2^24 and
+    against the default plan of the size above that."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    packed = factors[0] | (factors[1] << 8) | (factors[2] << 16)
+    extra = dict(group=2, streams=2) if batch > 2 else {}
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n, factors=packed, **extra)
+    assert plan.get("path") == 7 and plan.get("factors") == packed and which == lg % 2
+    if lg <= 24:
+        _check(oracle, y, oracle.dft_f64(x, n, -1), n)
+    else:
+        y0, _, _ = _run(fw, dev, queue, "Forward", x, n)
+        mx, l2 = oracle.compare(y, y0.astype(np.complex128))
+        assert mx <= 2e-6 and l2 <= 1e-6, (lg, mx, l2)
+    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, factors=packed, **extra)
+    _check(oracle, z, x.astype(np.complex128), n)
+
+
 @pytest.mark.parametrize("lg,factors,batch", [(19, (10, 9, 0), 5), (20, (10, 10, 0), 3), (21, (10, 11, 0), 3), (18, (9, 9, 0), 7),
                                               (17, (6, 11, 0), 9), (20, (9, 11, 0), 2)])
 def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
@@ -402,7 +425,7 @@ def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
 @pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (10, 6, 0)), (17, 8, (8, 9, 0)),
                                               (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (10, 8, 0)), (19, 2, (6, 6, 7)),
                                               (19, 3, (10, 9, 0)), (20, 3, (6, 6, 8)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
-                                              (22, 1, (7, 7, 8)), (24, 1, (10, 7, 7))])
+                                              (22, 1, (7, 7, 8)), (22, 2, (11, 11, 0)), (24, 1, (10, 7, 7))])
 def test_plan_picks_small_tiles_for_few_transforms(gpu, oracle, lg, batch, factors):
     """Latency regime (at most 2^20 samples per exec, a single 2^21, fewer than 4 of 2^20): balanced small tiles so that
     every CU gets work; above it the 1024-point first pass.  Either way the transform is the same."""
