@@ -16,22 +16,28 @@ namespace fwa {
 // (k_tile covers these lengths with 16 points per thread and two full-complex exchanges: 512-point rows were the slow
 // pass of the 2^19 plan, and 2048-point rows did not exist: 2^21 needed three passes.)
 // ---------------------------------------------------------------------------
-template <int LGN>
+template <int LGN, int RW = 16>
 struct Rows32 {
-    static constexpr int N = 1 << LGN, T = N / 32, WG = 16 * T;
+    static constexpr int N = 1 << LGN, T = N / 32, WG = RW * T;
     static constexpr int PN = N + N / 32;
     static constexpr int PNS = PN + ((17 - PN % 32) + 32) % 32;  // padded floats per row, = 17 mod 32
-    static constexpr int LDS_BYTES = 16 * PNS * 4;
+    static constexpr int LDS_BYTES = RW * PNS * 4;
 };
 
-template <int LGN, int DIR>
-__global__ __launch_bounds__((16 << (LGN - 5)), 4) void k_rows32(const v2f *__restrict__ in, v2f *__restrict__ out,
+// rows per workgroup: 16 (128-byte store segments); 8 at 2048-point rows -- 64-byte segments (the size of an L2 -> fabric
+// write request anyway) but two 512-thread workgroups per CU instead of one of 1024: 2^21 1.715 -> 1.633 ms, 2^22 1.892 ->
+// 1.845 ms; at 1024-point rows (two workgroups per CU either way) 8 rows are 3 % slower (profiles/round2/probe_rows32_8_rows.txt)
+constexpr int rows32_rows(int lgn) { return lgn == 11 ? 8 : 16; }
+
+template <int LGN, int DIR, int RW = 16>
+__global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__restrict__ in, v2f *__restrict__ out,
                                                                   const v2f *__restrict__ tw, uint32_t n1, uint64_t in_sb,
                                                                   uint64_t out_sb, float scale, uint32_t xcd_swizzle)
 {
     static_assert(LGN >= 9 && LGN <= 11, "k_rows32 covers row lengths 512 .. 2048");
-    using G = Rows32<LGN>;
+    using G = Rows32<LGN, RW>;
     constexpr int N = G::N, T = G::T, PNS = G::PNS;
+    constexpr int LGRW = RW == 8 ? 3 : 4;
     constexpr int R1 = (LGN == 9) ? 16 : 32;
     constexpr bool TWO = (32 * R1 == N);
     constexpr int R2 = TWO ? 1 : N / (32 * R1);
@@ -42,16 +48,16 @@ __global__ __launch_bounds__((16 << (LGN - 5)), 4) void k_rows32(const v2f *__re
     const uint32_t tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x;
     const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
-    const uint32_t tiles = n1 >> 4;
+    const uint32_t tiles = n1 >> LGRW;
     const uint32_t tile = bid % tiles;
     const uint64_t bt = bid / tiles;
     const uint32_t xf = tid / T, t = tid % T;  // loading role: row, butterfly
-    const uint32_t r = tid & 15, kk = tid >> 4;  // storing role
+    const uint32_t r = tid & (RW - 1), kk = tid >> LGRW;  // storing role
     float *lfw = lds + xf * PNS;
     const float *lfr_same = lfw;
     const float *lfr_t = lds + r * PNS;
     const __amdgpu_buffer_rsrc_t rin =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in + bt * in_sb + (uint64_t)tile * 16 * N), 0, 16u * N * 8u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in + bt * in_sb + (uint64_t)tile * RW * N), 0, (uint32_t)RW * N * 8u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + bt * out_sb, 0, n1 * (N * 8u), 0x00020000);
     const uint32_t voff = (xf * N + t) * 8;
 
@@ -73,7 +79,7 @@ __global__ __launch_bounds__((16 << (LGN - 5)), 4) void k_rows32(const v2f *__re
     twiddle_outputs<32, N, DIR>(x, tw, t);
     // transposed store role: output K2 of row r goes to element (16*tile + r) + n1*K2
     const uint32_t voff_o = (kk * n1 + r) * 8;
-    const uint32_t soff_o = tile * 128;
+    const uint32_t soff_o = tile * (RW * 8);
     const uint32_t kstep = n1 * 8;  // bytes per unit of K2
     if constexpr (TWO) {
         // -> last stage (radix R1, J = 32, s = 0) in the storing role: butterfly idx = kk + b*T of row r
@@ -244,11 +250,12 @@ template <int LGN, int DIR>
 static hipError_t launch_rows32_n(const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb, uint64_t out_sb,
                                   uint32_t n_transforms, float scale, uint32_t swz, hipStream_t st)
 {
-    using G = Rows32<LGN>;
-    const uint64_t blocks = (uint64_t)n_transforms * (n1 / 16);
+    constexpr int RW = rows32_rows(LGN);
+    using G = Rows32<LGN, RW>;
+    const uint64_t blocks = (uint64_t)n_transforms * (n1 / RW);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (blocks % 8) swz = 0;
-    hipLaunchKernelGGL((k_rows32<LGN, DIR>), dim3((uint32_t)blocks), dim3(G::WG), G::LDS_BYTES, st, in, out, tw, n1, in_sb,
+    hipLaunchKernelGGL((k_rows32<LGN, DIR, RW>), dim3((uint32_t)blocks), dim3(G::WG), G::LDS_BYTES, st, in, out, tw, n1, in_sb,
                        out_sb, scale, swz);
     return hipGetLastError();
 }
@@ -259,9 +266,9 @@ hipError_t prepare_rows32(uint32_t lg_l)
     hipError_t e = hipSuccess;
     auto set = [&](const void *k, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
     switch (lg_l) {
-        case 9: set(reinterpret_cast<const void *>(&k_rows32<9, FWD>), Rows32<9>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<9, INV>), Rows32<9>::LDS_BYTES); break;
-        case 10: set(reinterpret_cast<const void *>(&k_rows32<10, FWD>), Rows32<10>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<10, INV>), Rows32<10>::LDS_BYTES); break;
-        case 11: set(reinterpret_cast<const void *>(&k_rows32<11, FWD>), Rows32<11>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<11, INV>), Rows32<11>::LDS_BYTES); break;
+        case 9: set(reinterpret_cast<const void *>(&k_rows32<9, FWD, 16>), Rows32<9, 16>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<9, INV, 16>), Rows32<9, 16>::LDS_BYTES); break;
+        case 10: set(reinterpret_cast<const void *>(&k_rows32<10, FWD, 16>), Rows32<10, 16>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<10, INV, 16>), Rows32<10, 16>::LDS_BYTES); break;
+        case 11: set(reinterpret_cast<const void *>(&k_rows32<11, FWD, 8>), Rows32<11, 8>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<11, INV, 8>), Rows32<11, 8>::LDS_BYTES); break;
         default: return hipErrorInvalidValue;
     }
     return e;
