@@ -12,7 +12,8 @@ namespace fwa {
 // thread that was (row xf = tid / T, butterfly t = tid % T) while loading becomes (row r = tid % 16, butterfly
 // kk = tid / 16) for the last stage -- its outputs K2 then sit beside those of the 15 other rows of the same K2 and a
 // store instruction writes 128-byte segments.  Row buffers are skewed to 17 mod 32 floats so that the 16 rows read
-// by one instruction fall on different banks.  16*T threads (256 / 512 / 1024), 34 / 69 / 137 KiB of LDS.
+// by one instruction fall on different banks.  RW*T threads and RW*PNS*4 bytes of LDS: 256 / 34 KiB at 512-point rows,
+// 512 / 69 KiB at 1024, 512 / 68 KiB at 2048 (RW = 8 there, see rows32_rows).
 // (k_tile covers these lengths with 16 points per thread and two full-complex exchanges: 512-point rows were the slow
 // pass of the 2^19 plan, and 2048-point rows did not exist: 2^21 needed three passes.)
 // ---------------------------------------------------------------------------
