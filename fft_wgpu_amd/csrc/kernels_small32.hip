@@ -7,7 +7,7 @@ namespace fwa {
 // (Below 512 the same structure loses badly -- n/32 = 2 .. 8 threads per transform make every load instruction a
 // 16..64-byte-per-transform gather: 0.09 / 0.17 / 0.54 of the roofline at 64 / 128 / 256 against 0.70 for k_small16,
 // profiles/round2/sweep_small32_below_512.jsonl -- so k_small16 keeps n <= 256.)
-// n = 512 .. 32768: 32 points per thread, register stages 32 x 16 | 32 x 32 | 32 x 32 x 2 | 32 x 32 x 4 | 32 x 16 x 16 |
+// n = 512 .. 32768: 32 points per thread, register stages 32 x 16 | 32 x 32 | 32 x 32 x 2 | 32 x 32 x 4 | 32 x 32 x 8 |
 // 32 x 32 x 16 | 32 x 32 x 32, i.e. ONE exchange at 512 / 1024 and TWO above (k_small16: two / three), each through a
 // float buffer -- real parts, then imaginary parts.  n/32 threads per transform, 256-thread workgroups (512 / 1024 at
 // 16384 / 32768) with 33 KiB of LDS (66 / 132 KiB): 256 KiB of loads in flight per CU (k_small16 at 8192 / 16384:
@@ -25,9 +25,9 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
     constexpr int T = N / 32;                                   // threads per transform = radix-32 butterflies
     constexpr int WG = LGN <= 13 ? 256 : T;                     // workgroup size; XPW transforms per workgroup
     constexpr int XPW = WG / T;
-    constexpr int R1 = (LGN == 9 || LGN == 13) ? 16 : 32;       // second radix
+    constexpr int R1 = (LGN == 9) ? 16 : 32;       // second radix
     constexpr bool TWO = (32 * R1 == N);                        // n <= 1024: two stages, one exchange
-    constexpr int R2 = TWO ? 1 : N / (32 * R1);                 // third radix: 2, 4, 16, 16, 32 for 2^11 .. 2^15
+    constexpr int R2 = TWO ? 1 : N / (32 * R1);                 // third radix: 2, 4, 8, 16, 32 for 2^11 .. 2^15
     constexpr int B1 = 32 / R1;                                 // butterflies per thread in stages 1 and 2
     constexpr int J2 = 32 * R1;
     constexpr int PN = N + N / 32;                              // padded floats per transform
