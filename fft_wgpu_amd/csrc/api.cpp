@@ -181,13 +181,14 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
     if (n == (1u << 20) && !few) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
         // factors of 64..1024 each, 2048 for the rows of a two-pass plan (re-tunable: key "factors").  Throughput
-        // regime: two passes up to 2^19 and at 2^21 / 2^22 (2048-point passes), three otherwise; a 1024-point first pass (k_p1_gen) wherever the
+        // regime: two passes up to 2^19 and at 2^21 .. 2^23 (2048 / 4096-point passes), three otherwise; a 1024-point first pass (k_p1_gen) wherever the
         // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
         // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
-        if (!few && lg == 22) { lf[0] = lf[1] = 11; }  // 2048 x 2048: k_cols2048 + k_rows32
+        if (!few && lg == 22) { lf[0] = 10; lf[1] = 12; }       // 1024 x 4096: k_p1_gen + k_rows32 (8 rows of 4096 per workgroup)
+        else if (!few && lg == 23) { lf[0] = 11; lf[1] = 12; }  // 2048 x 4096: k_cols2048 + k_rows32
         else if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
         else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
-        else if (!few && lg >= 23) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
+        else if (!few && lg >= 24) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }  // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
@@ -1162,8 +1163,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         const uint32_t nf = f[2] ? 3 : 2;
         uint32_t sum = 0;
         for (uint32_t i = 0; i < nf; ++i) {
-            // 2048: as the first factor (k_cols2048) and as the second of two (k_rows32), n <= 2^28
-            const uint32_t top = (plan->lg <= 28 && (i == 0 || (nf == 2 && i == 1))) ? 11u : 10u;
+            // 2048: as the first factor (k_cols2048); 2048 / 4096: as the second of two (k_rows32); n <= 2^28
+            const uint32_t top = plan->lg > 28 ? 10u : (i == 0 ? 11u : ((nf == 2 && i == 1) ? 12u : 10u));
             if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: first, or second of two)");
             sum += f[i];
         }

@@ -5,7 +5,7 @@
 namespace fwa {
 
 // ---------------------------------------------------------------------------
-// k_rows32: the LAST pass of a two-pass plan n = N1 x L with L = 512, 1024 or 2048 -- the k_small32 network on 16
+// k_rows32: the LAST pass of a two-pass plan n = N1 x L with L = 512, 1024, 2048 or 4096 -- the k_small32 network on 16
 // adjacent rows (K1 = 16*tile .. +15, each a contiguous L-point transform in the slab, so the 16 rows of a tile are one
 // contiguous 16*L*8-byte chunk) with the transposed store X[K1 + N1*K2] of the four-step algorithm.  The transposition
 // costs nothing extra: the last register stage is free to pick its operands from ANY row's exchange buffer, so the
@@ -13,7 +13,7 @@ namespace fwa {
 // kk = tid / 16) for the last stage -- its outputs K2 then sit beside those of the 15 other rows of the same K2 and a
 // store instruction writes 128-byte segments.  Row buffers are skewed to 17 mod 32 floats so that the 16 rows read
 // by one instruction fall on different banks.  RW*T threads and RW*PNS*4 bytes of LDS: 256 / 34 KiB at 512-point rows,
-// 512 / 69 KiB at 1024, 512 / 68 KiB at 2048 (RW = 8 there, see rows32_rows).
+// 512 / 69 KiB at 1024, 512 / 68 KiB at 2048 and 1024 / 136 KiB at 4096 (RW = 8 there, see rows32_rows).
 // (k_tile covers these lengths with 16 points per thread and two full-complex exchanges: 512-point rows were the slow
 // pass of the 2^19 plan, and 2048-point rows did not exist: 2^21 needed three passes.)
 // ---------------------------------------------------------------------------
@@ -28,14 +28,14 @@ struct Rows32 {
 // rows per workgroup: 16 (128-byte store segments); 8 at 2048-point rows -- 64-byte segments (the size of an L2 -> fabric
 // write request anyway) but two 512-thread workgroups per CU instead of one of 1024: 2^21 1.715 -> 1.633 ms, 2^22 1.892 ->
 // 1.845 ms; at 1024-point rows (two workgroups per CU either way) 8 rows are 3 % slower (profiles/round2/probe_rows32_8_rows.txt)
-constexpr int rows32_rows(int lgn) { return lgn == 11 ? 8 : 16; }
+constexpr int rows32_rows(int lgn) { return lgn >= 11 ? 8 : 16; }
 
 template <int LGN, int DIR, int RW = 16>
 __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__restrict__ in, v2f *__restrict__ out,
                                                                   const v2f *__restrict__ tw, uint32_t n1, uint64_t in_sb,
                                                                   uint64_t out_sb, float scale, uint32_t xcd_swizzle)
 {
-    static_assert(LGN >= 9 && LGN <= 11, "k_rows32 covers row lengths 512 .. 2048");
+    static_assert(LGN >= 9 && LGN <= 12, "k_rows32 covers row lengths 512 .. 4096");
     using G = Rows32<LGN, RW>;
     constexpr int N = G::N, T = G::T, PNS = G::PNS;
     constexpr int LGRW = RW == 8 ? 3 : 4;
@@ -245,7 +245,7 @@ hipError_t launch_cols2048(int dir, bool out_is_ring, const v2f *in, v2f *out, c
     return hipLaunchKernel(cols2048_kernel(dir, out_is_ring), dim3((uint32_t)blocks), dim3(1024), args, cols2048_lds(), st);
 }
 
-bool rows32_supported(uint32_t lg_l) { return lg_l >= 9 && lg_l <= 11; }
+bool rows32_supported(uint32_t lg_l) { return lg_l >= 9 && lg_l <= 12; }
 
 template <int LGN, int DIR>
 static hipError_t launch_rows32_n(const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb, uint64_t out_sb,
@@ -270,6 +270,7 @@ hipError_t prepare_rows32(uint32_t lg_l)
         case 9: set(reinterpret_cast<const void *>(&k_rows32<9, FWD, 16>), Rows32<9, 16>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<9, INV, 16>), Rows32<9, 16>::LDS_BYTES); break;
         case 10: set(reinterpret_cast<const void *>(&k_rows32<10, FWD, 16>), Rows32<10, 16>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<10, INV, 16>), Rows32<10, 16>::LDS_BYTES); break;
         case 11: set(reinterpret_cast<const void *>(&k_rows32<11, FWD, 8>), Rows32<11, 8>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<11, INV, 8>), Rows32<11, 8>::LDS_BYTES); break;
+        case 12: set(reinterpret_cast<const void *>(&k_rows32<12, FWD, 8>), Rows32<12, 8>::LDS_BYTES); set(reinterpret_cast<const void *>(&k_rows32<12, INV, 8>), Rows32<12, 8>::LDS_BYTES); break;
         default: return hipErrorInvalidValue;
     }
     return e;
@@ -287,7 +288,7 @@ hipError_t launch_rows32(int dir, uint32_t lg_l, const v2f *in, v2f *out, const 
         return dir == FWD ? launch_rows32_n<L, FWD>(in, out, tw, n1, in_sb, out_sb, n_transforms, scale, xcd_swizzle, st) \
                           : launch_rows32_n<L, INV>(in, out, tw, n1, in_sb, out_sb, n_transforms, scale, xcd_swizzle, st)
     switch (lg_l) {
-        FWA_R32(9); FWA_R32(10); FWA_R32(11);
+        FWA_R32(9); FWA_R32(10); FWA_R32(11); FWA_R32(12);
         default: return hipErrorInvalidValue;
     }
 #undef FWA_R32

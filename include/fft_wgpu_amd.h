@@ -154,7 +154,7 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "path": 0 one-launch kernels (n <= 32768), 1 two-pass 2^20 pipeline (one launch per pass and group of
  *           transforms), 2 literal radix-2 recurrence (one launch per stage, kernel/fft.wgsl:27-62; forced only),
  *           3 normalize, 4 identity (n = 1), 5 the 2^20 pipeline as ONE persistent launch with a small ring (opt-in),
- *           7 tiled pipeline: two passes at 2^16..2^19, 2^21 and 2^22, three at 2^23..2^30 and at 2^20 with fewer than 4 transforms,
+ *           7 tiled pipeline: two passes at 2^16..2^19 and 2^21..2^23, three at 2^24..2^30 and at 2^20 with fewer than 4 transforms,
  *           8 both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2 (opt-in),
  *   "factors": log2(N1) | log2(N2) << 8 | log2(N3) << 16 of a multi-pass plan,
  *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's twiddle tables),
@@ -163,8 +163,8 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "depth", "ring_slots", "wgs" (path 5), "max_teams", "wgs" (path 8),
  *   "p1_gen" (tiled plans whose first factor is 1024: 1 = the 2^20 pipeline's column kernel at run-time
  *   pitch as pass A (default), 0 = the generic tile kernel),
- *   "rows32" (two-pass tiled plans whose second factor is 512 .. 2048: 1 = 32-point-per-thread row kernel with the
- *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 exists only in the former),
+ *   "rows32" (two-pass tiled plans whose second factor is 512 .. 4096: 1 = 32-point-per-thread row kernel with the
+ *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 and 4096 exist only in the former),
  *   "small_reg" (n <= 32768: 1 = default: linear 32-KiB chunks staged through LDS for n = 4 .. 256, 32 points per
  *           thread from 512; 3 = the direct-addressing 16-point kernels up to 4096 (A/B); 2 = wave-shuffle exchange at
  *           32/64/128; 0 = LDS radix-2 kernel up to 4096),

@@ -106,16 +106,17 @@ def test_path_selection_host_logic():
     assert fw.describe_path(1 << 24) == (7, [1024, 128, 128])   # config C5: 1024-point first pass (k_p1_gen)
     assert fw.describe_path(1 << 16) == (7, [1024, 64])
     assert fw.describe_path(1 << 19) == (7, [1024, 512])
-    assert fw.describe_path(1 << 22) == (7, [2048, 2048])       # two passes: k_cols2048 + k_rows32
+    assert fw.describe_path(1 << 22) == (7, [1024, 4096])       # two passes: k_p1_gen + k_rows32 (4096-point rows)
+    assert fw.describe_path(1 << 23) == (7, [2048, 4096])       # two passes: k_cols2048 + k_rows32
     assert fw.describe_path(1 << 30) == (7, [1024, 1024, 1024])
     assert fw.describe_path(1 << 21) == (7, [1024, 2048])       # two passes: 2048-point rows in k_rows32
     for lg in list(range(16, 20)) + list(range(21, 31)):
         path, f = fw.describe_path(1 << lg)
-        assert path == 7 and all(64 <= x <= (2048 if lg in (21, 22) else 1024) for x in f)
+        assert path == 7 and all(64 <= x <= (4096 if lg in (21, 22, 23) else 1024) for x in f)
         prod = 1
         for x in f:
             prod *= x
-        assert prod == 1 << lg and len(f) == (2 if lg <= 19 or lg in (21, 22) else 3)
+        assert prod == 1 << lg and len(f) == (2 if lg <= 19 or lg in (21, 22, 23) else 3)
     with pytest.raises(fw.FwaError) as e:
         fw.describe_path(1000)
     assert e.value.status == 1

@@ -293,7 +293,7 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch):
     r = oracle.dft_f64(x, n, -1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n, group=2, streams=2)
     assert plan.get("path") == 7 and plan.get("group") == 2 and which == lg % 2
-    assert (plan.get("factors") >> 16 == 0) == (lg <= 19 or lg in (21, 22))   # two passes up to 2^19 and at 2^21, 2^22
+    assert (plan.get("factors") >> 16 == 0) == (lg <= 19 or lg in (21, 22, 23))   # two passes up to 2^19 and at 2^21 .. 2^23
     _check(oracle, y, r, n)
     z, _, _ = _run(fw, dev, queue, "Inverse", y, n, group=2, streams=2)
     _check(oracle, z, x.astype(np.complex128), n)
@@ -398,6 +398,7 @@ def test_first_pass_2048_column_kernel(gpu, oracle, lg, factors, batch):
 
 
 @pytest.mark.parametrize("lg,factors,batch", [(19, (10, 9, 0), 5), (20, (10, 10, 0), 3), (21, (10, 11, 0), 3), (18, (9, 9, 0), 7),
+                                              (22, (10, 12, 0), 3), (23, (11, 12, 0), 2), (18, (6, 12, 0), 9),
                                               (17, (6, 11, 0), 9), (20, (9, 11, 0), 2)])
 def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
     """Key "rows32": two-pass tiled plans whose second factor is 512 / 1024 / 2048 run k_rows32 (32 points per thread, 16
@@ -425,7 +426,7 @@ def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
 @pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (10, 6, 0)), (17, 8, (8, 9, 0)),
                                               (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (10, 8, 0)), (19, 2, (6, 6, 7)),
                                               (19, 3, (10, 9, 0)), (20, 3, (6, 6, 8)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
-                                              (22, 1, (7, 7, 8)), (22, 2, (11, 11, 0)), (24, 1, (10, 7, 7))])
+                                              (22, 1, (7, 7, 8)), (22, 2, (10, 12, 0)), (23, 1, (11, 12, 0)), (24, 1, (10, 7, 7))])
 def test_plan_picks_small_tiles_for_few_transforms(gpu, oracle, lg, batch, factors):
     """Latency regime (at most 2^20 samples per exec, a single 2^21, fewer than 4 of 2^20): balanced small tiles so that
     every CU gets work; above it the 1024-point first pass.  Either way the transform is the same."""
