@@ -185,7 +185,7 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
         // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
         // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
         if (!few && lg == 22) { lf[0] = 10; lf[1] = 12; }       // 1024 x 4096: k_p1_gen + k_rows32 (8 rows of 4096 per workgroup)
-        else if (!few && lg == 23) { lf[0] = 11; lf[1] = 12; }  // 2048 x 4096: k_cols2048 + k_rows32
+        else if (!few && lg == 23) { lf[0] = 11; lf[1] = 12; }  // 2048 x 4096: k_cols32 + k_rows32
         else if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
         else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
         else if (!few && lg >= 24) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
@@ -467,11 +467,11 @@ int32_t setup_path(fwa_plan *p)
                 hipError_t re = fwa::prepare_rows32(p->lf[1]);
                 if (re != hipSuccess) return fail_hip(ctx, re, "hipFuncSetAttribute(max dynamic LDS)");
             }
-            if (i == 0 && p->lf[0] == 11) {
-                hipError_t ce = fwa::prepare_cols2048();
+            if (i == 0 && fwa::cols32_supported(p->lf[0])) {
+                hipError_t ce = fwa::prepare_cols32(p->lf[0]);
                 if (ce != hipSuccess) return fail_hip(ctx, ce, "hipFuncSetAttribute(max dynamic LDS)");
             }
-            if (p->lf[i] > 10) continue;  // 2048-point passes: k_cols2048 / k_rows32 only
+            if (p->lf[i] > 10) continue;  // 2048 / 4096-point passes: k_cols32 / k_rows32 only
             hipError_t pe = fwa::prepare_tile(p->lf[i], 16);
             if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
         }
@@ -1015,9 +1015,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
                 ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
                 hipError_t le;
-                if (plan->lf[0] == 11)
-                    le = fwa::launch_cols2048(dir, true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
-                                              (uint32_t)cnt, ta.xcd_swizzle, s);
+                if (plan->lf[0] > 10)
+                    le = fwa::launch_cols32(dir, plan->lf[0], true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N,
+                                            N, (uint32_t)cnt, ta.xcd_swizzle, s);
                 else if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
                     le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
                                             (uint32_t)cnt, ta.xcd_swizzle, s);
@@ -1163,9 +1163,9 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         const uint32_t nf = f[2] ? 3 : 2;
         uint32_t sum = 0;
         for (uint32_t i = 0; i < nf; ++i) {
-            // 2048: as the first factor (k_cols2048); 2048 / 4096: as the second of two (k_rows32); n <= 2^28
+            // 2048: as the first factor (k_cols32); 2048 / 4096: as the second of two (k_rows32); n <= 2^28
             const uint32_t top = plan->lg > 28 ? 10u : (i == 0 ? 11u : ((nf == 2 && i == 1) ? 12u : 10u));
-            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: first, or second of two)");
+            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: first; 2^11, 2^12: second of two)");
             sum += f[i];
         }
         if (sum != plan->lg || (value >> 24)) return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");

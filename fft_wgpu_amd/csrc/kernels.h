@@ -26,12 +26,13 @@ bool rows32_supported(uint32_t lg_l);
 hipError_t prepare_rows32(uint32_t lg_l);
 hipError_t launch_rows32(int dir, uint32_t lg_l, const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb,
                          uint64_t out_sb, uint32_t n_transforms, float scale, uint32_t xcd_swizzle, hipStream_t st);
-// pass A with a 2048-point first factor (n = 2048 * pitch <= 2^28): 16 adjacent columns per workgroup, matrix layout out,
-// four-step twiddle of domain n (kernels_rows32.hip: k_cols2048); tw = half table of W_2048
-hipError_t prepare_cols2048();
-hipError_t launch_cols2048(int dir, bool out_is_ring, const v2f *in, v2f *out, const v2f *tw, const v2f *tw_lo, const v2f *tw_hi,
-                           uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms, uint32_t xcd_swizzle,
-                           hipStream_t st);
+// pass A with a 2048-point first factor (lg_l = 11, n = 2048 * pitch <= 2^28): 16 adjacent columns
+// per workgroup, matrix layout out, four-step twiddle of domain n (kernels_rows32.hip: k_cols32); tw = half table of W_{2^lg_l}
+bool cols32_supported(uint32_t lg_l);
+hipError_t prepare_cols32(uint32_t lg_l);
+hipError_t launch_cols32(int dir, uint32_t lg_l, bool out_is_ring, const v2f *in, v2f *out, const v2f *tw, const v2f *tw_lo,
+                         const v2f *tw_hi, uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms,
+                         uint32_t xcd_swizzle, hipStream_t st);
 enum { TILE_COLS = 0, TILE_ROWS_T = 1 };
 enum { ROLE_FIRST = 1, ROLE_MIDDLE = 2, ROLE_LAST = 3 };  // cache-policy role of a tiled pass
 

@@ -1,5 +1,5 @@
 // kernels_rows32.hip -- the 32-point-per-thread network of k_small32 as passes of the multi-pass plans: k_rows32 (last
-// pass: 512 / 1024 / 2048-point rows with the transposed store) and k_cols2048 (first pass: 2048-point columns).
+// pass: 512 .. 4096-point rows with the transposed store) and k_cols32 (first pass: 2048 / 4096-point columns).
 #include "small32_common.h"
 
 namespace fwa {
@@ -132,45 +132,51 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
 }
 
 // ---------------------------------------------------------------------------
-// k_cols2048: pass A of a plan whose first factor is 2048 (2^22 = 2048 x 2048 in two passes): the k_small32 network
-// (32 x 32 x 2) on 16 adjacent COLUMNS of a 2048-row matrix at run-time pitch -- the "row r = tid % 16, butterfly
-// kk = tid / 16" role of k_rows32 for every stage, so each load / store instruction moves 128-byte row segments.
-// Output in the matrix layout, multiplied by the four-step factor W_n^{col*k1} = A[kk][c] * B[j][c] (k1 = kk + off_j),
-// both from the two-level table of domain n as in k_p1_gen.  1024 threads, 137 + 4 KiB of LDS, one workgroup per CU.
+// k_cols32: pass A of a plan whose first factor is 2048 or 4096: the k_small32 network (32 x 32 x 2 | 32 x 32 x 4) on CW
+// adjacent COLUMNS of a 2^LGN-row matrix at run-time pitch -- the "column c = tid % CW, butterfly kk = tid / CW" role
+// for every stage, so each load / store instruction moves CW*8-byte row segments.  Output in the matrix layout,
+// multiplied by the four-step factor W_n^{col*k1} = A[kk][c] * B[j][c] (k1 = kk + off_j), both from the two-level table
+// of domain n as in k_p1_gen.  1024 threads, one workgroup per CU:
+//   2048 rows x 16 columns (128-byte segments), 137 + 4 KiB of LDS -- the only instantiation that ships;
+//   4096 rows x  8 columns ( 64-byte segments: half a cache line per row) was built and measured: correct, and 40-50 %
+//   slower than three passes (C5 0.204 ms against 0.137; profiles/round2/sweep_cols4096_negative.jsonl) -- half-line
+//   READS cost what half-line writes (k_rows32 at 2048 / 4096-point rows) do not.
 // ---------------------------------------------------------------------------
-template <int DIR, int AUX_OUT>
-__global__ __launch_bounds__(1024, 4) void k_cols2048(const v2f *__restrict__ in, v2f *__restrict__ out,
-                                                      const v2f *__restrict__ tw, const v2f *__restrict__ tw_lo,
-                                                      const v2f *__restrict__ tw_hi, uint32_t pitch, uint64_t in_sb,
-                                                      uint64_t out_sb, uint32_t xcd_swizzle)
+template <int LGN, int CW, int DIR, int AUX_OUT>
+__global__ __launch_bounds__(1024, 4) void k_cols32(const v2f *__restrict__ in, v2f *__restrict__ out,
+                                                    const v2f *__restrict__ tw, const v2f *__restrict__ tw_lo,
+                                                    const v2f *__restrict__ tw_hi, uint32_t pitch, uint64_t in_sb,
+                                                    uint64_t out_sb, uint32_t xcd_swizzle)
 {
-    using G = Rows32<11>;
-    constexpr int N = G::N, T = G::T, PNS = G::PNS, J2 = 1024;
+    using G = Rows32<LGN, CW>;
+    static_assert(G::WG == 1024 && (CW == 8 || CW == 16), "1024 threads");
+    constexpr int N = G::N, T = G::T, PNS = G::PNS, J2 = 1024, R2 = N / 1024, B2 = 32 / R2;
+    constexpr int LGCW = CW == 8 ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     v2f *two = reinterpret_cast<v2f *>(smem + G::LDS_BYTES);
     const uint32_t tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x;
     const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
-    const uint32_t tiles = pitch >> 4;
+    const uint32_t tiles = pitch >> LGCW;
     const uint32_t tile = bid % tiles;
     const uint64_t bt = bid / tiles;
-    const uint32_t c = tid & 15, kk = tid >> 4;  // column of the tile, butterfly (0 .. 63)
+    const uint32_t c = tid & (CW - 1), kk = tid >> LGCW;  // column of the tile, butterfly (0 .. T-1)
     float *lf = lds + c * PNS;
     const uint32_t tbytes = pitch * (N * 8u);  // n * 8 <= 2^31 (launcher)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(in + bt * in_sb), 0, tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + bt * out_sb, 0, tbytes, 0x00020000);
     const uint32_t voff = (kk * pitch + c) * 8;
-    const uint32_t soff = tile * 128;
+    const uint32_t soff = tile * (CW * 8);
     const uint32_t rstep = pitch * 8;  // bytes per matrix row
 
     v2f x[32];
     static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, voff, soff + (m * T) * rstep); });
-    const uint32_t col = tile * 16 + c;
+    const uint32_t col = tile * CW + c;
     auto look = [&](uint32_t e) { return cmul(tw_hi[e >> 10], tw_lo[e & 1023]); };  // e < n
-    if (kk < 32) {  // B[j][c] = W_n^{col * off_j}, off_j = (j & 15) * 64 + (j >> 4) * 1024
-        const uint32_t off = (kk & 15) * T + (kk >> 4) * J2;
-        two[kk * 16 + c] = look(col * off);
+    if (kk < 32) {  // B[j][c] = W_n^{col * off_j}, off_j = (j % B2) * T + (j / B2) * 1024
+        const uint32_t off = (kk % B2) * T + (kk / B2) * J2;
+        two[kk * CW + c] = look(col * off);
     }
     const v2f A = look(col * kk);
 
@@ -201,48 +207,55 @@ __global__ __launch_bounds__(1024, 4) void k_cols2048(const v2f *__restrict__ in
         return P((uint32_t)brev<32>(i) * 32);
     }, rbase, [&](auto i_) {
         constexpr uint32_t i = decltype(i_)::value;
-        return P((i / 2) * T + (i % 2) * (N / 2));
+        return P((i / R2) * T + (i % R2) * (N / R2));
     });
-    static_for<0, 16>([&](auto b_) {
+    static_for<0, B2>([&](auto b_) {
         constexpr int b = decltype(b_)::value;
-        v2f(&z)[2] = *reinterpret_cast<v2f(*)[2]>(&x[b * 2]);
-        fft_reg<2, DIR>(z);
-        static_for<0, 2>([&](auto q_) {
+        v2f(&z)[R2] = *reinterpret_cast<v2f(*)[R2]>(&x[b * R2]);
+        fft_reg<R2, DIR>(z);
+        static_for<0, R2>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
-            const v2f w = cmul(A, two[(q * 16 + b) * 16 + c]);
-            buf_store<AUX_OUT>(cmul_tw<DIR>(z[brev<2>(q)], w), rout, voff, soff + (b * T + q * J2) * rstep);
+            const v2f w = cmul(A, two[(q * B2 + b) * CW + c]);
+            buf_store<AUX_OUT>(cmul_tw<DIR>(z[brev<R2>(q)], w), rout, voff, soff + (b * T + q * J2) * rstep);
         });
     });
 }
 
-static int cols2048_lds() { return Rows32<11>::LDS_BYTES + 32 * 16 * 8; }
-static const void *cols2048_kernel(int dir, bool ring)
+template <int LGN, int CW>
+static int cols32_lds() { return Rows32<LGN, CW>::LDS_BYTES + 32 * CW * 8; }
+template <int LGN, int CW>
+static const void *cols32_kernel(int dir, bool ring)
 {
-    return dir == FWD ? (ring ? reinterpret_cast<const void *>(&k_cols2048<FWD, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols2048<FWD, AUX_NT>))
-                      : (ring ? reinterpret_cast<const void *>(&k_cols2048<INV, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols2048<INV, AUX_NT>));
+    return dir == FWD ? (ring ? reinterpret_cast<const void *>(&k_cols32<LGN, CW, FWD, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols32<LGN, CW, FWD, AUX_NT>))
+                      : (ring ? reinterpret_cast<const void *>(&k_cols32<LGN, CW, INV, AUX_SC1>) : reinterpret_cast<const void *>(&k_cols32<LGN, CW, INV, AUX_NT>));
 }
 
-hipError_t prepare_cols2048()
+bool cols32_supported(uint32_t lg_l) { return lg_l == 11; }
+
+hipError_t prepare_cols32(uint32_t lg_l)
 {
     hipError_t e = hipSuccess;
     for (int dir : {FWD, INV})
         for (bool ring : {true, false})
-            if (e == hipSuccess) e = hipFuncSetAttribute(cols2048_kernel(dir, ring), hipFuncAttributeMaxDynamicSharedMemorySize, cols2048_lds());
-    return e;
+            if (e == hipSuccess && lg_l == 11)
+                e = hipFuncSetAttribute(cols32_kernel<11, 16>(dir, ring), hipFuncAttributeMaxDynamicSharedMemorySize, cols32_lds<11, 16>());
+    return cols32_supported(lg_l) ? e : hipErrorInvalidValue;
 }
 
-// n = 2048 * pitch <= 2^28 per transform; tw = half table of W_2048, (tw_lo, tw_hi) = two-level table of W_n
-hipError_t launch_cols2048(int dir, bool out_is_ring, const v2f *in, v2f *out, const v2f *tw, const v2f *tw_lo, const v2f *tw_hi,
-                           uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms, uint32_t xcd_swizzle,
-                           hipStream_t st)
+// n = 2^lg_l * pitch <= 2^28 per transform; tw = half table of W_{2^lg_l}, (tw_lo, tw_hi) = two-level table of W_n
+hipError_t launch_cols32(int dir, uint32_t lg_l, bool out_is_ring, const v2f *in, v2f *out, const v2f *tw, const v2f *tw_lo,
+                         const v2f *tw_hi, uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms,
+                         uint32_t xcd_swizzle, hipStream_t st)
 {
     if (n_transforms == 0) return hipSuccess;
-    if (pitch < 16 || pitch > (1u << 17) || (pitch & (pitch - 1))) return hipErrorInvalidValue;
-    const uint64_t blocks = (uint64_t)n_transforms * (pitch / 16);
+    if (!cols32_supported(lg_l)) return hipErrorInvalidValue;
+    const uint32_t cw = 16;
+    if (pitch < 16 || ((uint64_t)pitch << lg_l) > (1ull << 28) || (pitch & (pitch - 1))) return hipErrorInvalidValue;
+    const uint64_t blocks = (uint64_t)n_transforms * (pitch / cw);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (blocks % 8) xcd_swizzle = 0;
     void *args[] = {&in, &out, &tw, &tw_lo, &tw_hi, &pitch, &in_sb, &out_sb, &xcd_swizzle};
-    return hipLaunchKernel(cols2048_kernel(dir, out_is_ring), dim3((uint32_t)blocks), dim3(1024), args, cols2048_lds(), st);
+    return hipLaunchKernel(cols32_kernel<11, 16>(dir, out_is_ring), dim3((uint32_t)blocks), dim3(1024), args, cols32_lds<11, 16>(), st);
 }
 
 bool rows32_supported(uint32_t lg_l) { return lg_l >= 9 && lg_l <= 12; }

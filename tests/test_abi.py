@@ -107,7 +107,7 @@ def test_path_selection_host_logic():
     assert fw.describe_path(1 << 16) == (7, [1024, 64])
     assert fw.describe_path(1 << 19) == (7, [1024, 512])
     assert fw.describe_path(1 << 22) == (7, [1024, 4096])       # two passes: k_p1_gen + k_rows32 (4096-point rows)
-    assert fw.describe_path(1 << 23) == (7, [2048, 4096])       # two passes: k_cols2048 + k_rows32
+    assert fw.describe_path(1 << 23) == (7, [2048, 4096])       # two passes: k_cols32 + k_rows32
     assert fw.describe_path(1 << 30) == (7, [1024, 1024, 1024])
     assert fw.describe_path(1 << 21) == (7, [1024, 2048])       # two passes: 2048-point rows in k_rows32
     for lg in list(range(16, 20)) + list(range(21, 31)):

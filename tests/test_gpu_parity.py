@@ -377,7 +377,7 @@ def test_first_pass_1024_column_kernel(gpu, oracle, lg, factors, batch):
 @pytest.mark.parametrize("lg,factors,batch", [(22, (11, 11, 0), 3), (21, (11, 10, 0), 2), (17, (11, 6, 0), 9), (24, (11, 6, 7), 1),
                                               (28, (11, 8, 9), 1)])
 def test_first_pass_2048_column_kernel(gpu, oracle, lg, factors, batch):
-    """k_cols2048: pass A of plans whose first factor is 2048 (the default at 2^22 = 2048 x 2048; any other
+    """k_cols32: pass A of plans whose first factor is 2048 (the default at 2^23 = 2048 x 4096; any other
     factorisation through the "factors" key), forward and inverse, ragged groups, against the f64 DFT up to 2^24 and
     against the default plan of the size above that."""
     fw, dev, queue = gpu
