@@ -224,7 +224,8 @@ def main():
                          # (launches of different chains overlap: sum of durations / chains = exec time)
                          "per_launch": {"launches": launches, "chains": chains, "avg_launch_us": avg_launch_us,
                                         "algorithmic_bytes": launch_bytes,
-                                        "achieved_GBps_one_launch": launch_bytes / (avg_launch_us * 1e-6) / 1e9},
+                                        "achieved_GBps_one_launch": launch_bytes / (avg_launch_us * 1e-6) / 1e9,
+                                        "traffic_bytes": (traffic / launches) if traffic else None},
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
                          "copy_ceiling_GBps_same_run": copy_gbps},
             "cpu_baseline": cpu,
