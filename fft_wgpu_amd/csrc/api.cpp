@@ -68,6 +68,10 @@ struct fwa_ctx {
     std::vector<std::pair<uint64_t, void *>> free_rings;  // rings of destroyed plans, oldest first
     uint64_t free_ring_bytes = 0;
     int64_t n_table_builds = 0, n_table_hits = 0, n_ring_allocs = 0, n_ring_reuses = 0, last_plan_create_us = 0;
+    // Internal chain streams of the pipelined paths: created once per context, shared by every plan, and checked at
+    // creation to run kernels side by side (chain_streams() below).
+    std::vector<hipStream_t> chains;
+    int64_t n_chain_checks = 0, n_chain_rejects = 0, chain_pair_us = 0, chain_single_us = 0;
 };
 struct fwa_stream {
     fwa_ctx *ctx = nullptr;
@@ -110,10 +114,13 @@ struct fwa_plan {
                                    // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
     int64_t rows32 = 1;            // two-pass tiled plans with a 512..2048-point second factor: 1 = k_rows32 as last pass
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
+    int64_t colsw = 0;             // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) as pass A, 0 = k_tile
+    int64_t tile_ring = 1;         // k_colsw + k_rows32: 1 = tile-contiguous ring slab, 0 = matrix layout
     int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_last = nullptr;  // recorded on the caller's stream by every exec that used the ring (fwa_plan_destroy waits for it)
     // persistent 2^20 pipeline (PATH_RING_1M)
     uint32_t *ring_ctl = nullptr;  // ticket, error word, per-transform hand-off counters
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
@@ -171,9 +178,10 @@ uint32_t ilog2(uint32_t n)
 //    smallest tiles instead -- balanced two passes up to 2^17, balanced three passes of 64/128-point tiles above
 //    (2^16 x 1: 11.9 us against 16.2; 2^18 x 1: 12.7 against 18.4; 2^20 x 1: 19 against 24).
 constexpr uint64_t FEW_1M = 4;
-int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
+int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3], bool *colsw = nullptr)
 {
     lf[0] = lf[1] = lf[2] = 0;
+    if (colsw) *colsw = false;
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
@@ -184,11 +192,17 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3])
         // regime: two passes up to 2^19 and at 2^21 .. 2^23 (2048 / 4096-point passes), three otherwise; a 1024-point first pass (k_p1_gen) wherever the
         // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
         // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
+        // Round 3 (profiles/round3/sweep_colsw_32GiB.jsonl, sweep_factors_24_28_colsw.jsonl): short columns in wide tiles
+        // (k_colsw: 256 x 64 / 512 x 32, 512- / 256-byte row segments) beat the 1024 x 16 tile of k_p1_gen as pass A
+        // wherever the last pass keeps <= 1024-point rows: 2^16 .. 2^19 +7-9 %, three-pass sizes 2^24 .. 2^28 +2-16 %.
         if (!few && lg == 22) { lf[0] = 10; lf[1] = 12; }       // 1024 x 4096: k_p1_gen + k_rows32 (8 rows of 4096 per workgroup)
         else if (!few && lg == 23) { lf[0] = 11; lf[1] = 12; }  // 2048 x 4096: k_cols32 + k_rows32
         else if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
-        else if (!few && (lg <= 19 || lg == 21)) { lf[0] = 10; lf[1] = lg - 10; }
-        else if (!few && lg >= 24) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
+        else if (!few && lg <= 18) { lf[0] = 8; lf[1] = lg - 8; if (colsw) *colsw = true; }   // 256 x (256 .. 1024)
+        else if (!few && lg == 19) { lf[0] = 9; lf[1] = 10; if (colsw) *colsw = true; }       // 512 x 1024
+        else if (!few && lg == 21) { lf[0] = 10; lf[1] = lg - 10; }
+        else if (!few && lg >= 24 && lg <= 28) { lf[0] = 9; lf[1] = (lg - 9) / 2; lf[2] = lg - 9 - lf[1]; if (colsw) *colsw = true; }
+        else if (!few && lg >= 29) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
         else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }  // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
@@ -297,7 +311,7 @@ void *pool_take(fwa_ctx *ctx, uint64_t bytes)
 
 void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
 {
-    for (auto s : pl.streams) (void)hipStreamDestroy(s);
+    // pl.streams are borrowed from the context (ctx->chains)
     for (auto e : pl.done) (void)hipEventDestroy(e);
     pl.streams.clear();
     pl.done.clear();
@@ -319,6 +333,75 @@ void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
         pl.ring = nullptr;
         pl.ring_bytes = 0;
     }
+}
+
+// The chain streams.  Two HIP streams do not always run their kernels side by side on this stack: which hardware queue
+// a new stream lands on depends on what the process created and destroyed before, and a pair that shares one runs the two
+// chains of a pipelined plan strictly one after the other -- every exec of such a plan took the single-chain time
+// (+15 %: profiles/round3/probe_plan_instance_modes.txt).  So the streams are created ONCE per context, and each new one
+// is accepted only if a memory-free spin kernel on it overlaps the same kernel on all chains accepted before it
+// (pair time < 1.5 x single); a rejected stream stays alive until the search ends so that the runtime cannot hand the
+// same queue back.  Best effort: after 6 rejections the last candidate is kept (a context with more chains than the
+// runtime has hardware queues cannot overlap them all).
+int32_t chain_streams(fwa_ctx *ctx, size_t n)
+{
+    if (ctx->chains.size() >= n) return FWA_OK;
+    constexpr uint32_t TICKS = 4000, BLOCKS = 256;  // 40 us, one wave per CU
+    hipEvent_t e0 = nullptr, e1 = nullptr, fork = nullptr;
+    std::vector<hipEvent_t> done;
+    std::vector<hipStream_t> rejected;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    auto timed = [&](const std::vector<hipStream_t> &set, float *us) {  // spin on every stream of `set`, forked from / joined to the null stream
+        float best = 1e30f;
+        for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+            while (done.size() < set.size() && e == hipSuccess) {
+                hipEvent_t d;
+                e = hipEventCreateWithFlags(&d, hipEventDisableTiming);
+                if (e == hipSuccess) done.push_back(d);
+            }
+            if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(fork, nullptr);
+            for (size_t i = 0; i < set.size() && e == hipSuccess; ++i) {
+                e = hipStreamWaitEvent(set[i], fork, 0);
+                if (e == hipSuccess) e = fwa::launch_spin(TICKS, BLOCKS, set[i]);
+                if (e == hipSuccess) e = hipEventRecord(done[i], set[i]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, done[i], 0);
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (ms * 1e3f < best) best = ms * 1e3f;
+        }
+        *us = best;
+    };
+    while (ctx->chains.size() < n && e == hipSuccess) {
+        hipStream_t cand = nullptr;
+        e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        std::vector<hipStream_t> set = ctx->chains;
+        set.push_back(cand);
+        float single = 0, all = 0;
+        timed({cand}, &single);
+        if (set.size() > 1) timed(set, &all);
+        ++ctx->n_chain_checks;
+        const bool overlaps = set.size() == 1 || all < single + 0.5f * (TICKS * 0.01f);
+        if (e == hipSuccess && (overlaps || rejected.size() >= 6)) {
+            ctx->chains.push_back(cand);
+            ctx->chain_single_us = (int64_t)single;
+            if (set.size() > 1) ctx->chain_pair_us = (int64_t)all;
+        } else {
+            rejected.push_back(cand);
+            ++ctx->n_chain_rejects;
+        }
+    }
+    for (auto s : rejected) (void)hipStreamDestroy(s);
+    for (auto d : done) (void)hipEventDestroy(d);
+    for (auto ev : {e0, e1, fork}) if (ev) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail_hip(ctx, e, "chain stream setup");
+    return FWA_OK;
 }
 
 Pipeline take_pipeline(fwa_plan *p)
@@ -404,19 +487,22 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
             ++ctx->n_ring_allocs;
         }
         if (n_streams > 1) {
+            int32_t cs = chain_streams(ctx, (size_t)n_streams);
+            if (cs) return bail(cs);
             hipError_t e = hipEventCreateWithFlags(&pl.fork, hipEventDisableTiming);
             if (e != hipSuccess) { pl.fork = nullptr; return bail(fail_hip(ctx, e, "hipEventCreate")); }
             for (int64_t i = 0; i < n_streams; ++i) {
-                hipStream_t s;
                 hipEvent_t ev;
-                e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-                if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipStreamCreate"));
-                pl.streams.push_back(s);
+                pl.streams.push_back(ctx->chains[(size_t)i]);
                 e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
                 if (e != hipSuccess) return bail(fail_hip(ctx, e, "hipEventCreate"));
                 pl.done.push_back(ev);
             }
         }
+    }
+    if (!p->ev_last) {
+        hipError_t e = hipEventCreateWithFlags(&p->ev_last, hipEventDisableTiming);
+        if (e != hipSuccess) { p->ev_last = nullptr; return bail(fail_hip(ctx, e, "hipEventCreate")); }
     }
     Pipeline old = take_pipeline(p);
     destroy_pipeline_objects(ctx, old, true);
@@ -469,6 +555,10 @@ int32_t setup_path(fwa_plan *p)
             }
             if (i == 0 && fwa::cols32_supported(p->lf[0])) {
                 hipError_t ce = fwa::prepare_cols32(p->lf[0]);
+                if (ce != hipSuccess) return fail_hip(ctx, ce, "hipFuncSetAttribute(max dynamic LDS)");
+            }
+            if (i == 0 && fwa::colsw_supported(p->lf[0])) {
+                hipError_t ce = fwa::prepare_colsw(p->lf[0]);
                 if (ce != hipSuccess) return fail_hip(ctx, ce, "hipFuncSetAttribute(max dynamic LDS)");
             }
             if (p->lf[i] > 10) continue;  // 2048 / 4096-point passes: k_cols32 / k_rows32 only
@@ -539,6 +629,7 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
             HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
         }
     }
+    if (plan->ev_last) HIP_TRY(ctx, hipEventRecord(plan->ev_last, st));
     return FWA_OK;
 }
 
@@ -613,6 +704,7 @@ int32_t fwa_ctx_destroy(fwa_ctx *ctx)
     if (!ctx) return FWA_OK;
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->free_rings) (void)hipFree(kv.second);
+    for (auto s : ctx->chains) (void)hipStreamDestroy(s);
     ctx->tables.clear();
     delete ctx;
     return FWA_OK;
@@ -637,6 +729,11 @@ int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
     else if (k == "ring_reuses") *value = ctx->n_ring_reuses;
     else if (k == "last_plan_create_us") *value = ctx->last_plan_create_us;
     else if (k == "pooled_ring_bytes") *value = (int64_t)ctx->free_ring_bytes;
+    else if (k == "chain_streams") *value = (int64_t)ctx->chains.size();
+    else if (k == "chain_checks") *value = ctx->n_chain_checks;
+    else if (k == "chain_rejects") *value = ctx->n_chain_rejects;
+    else if (k == "chain_pair_us") *value = ctx->chain_pair_us;
+    else if (k == "chain_single_us") *value = ctx->chain_single_us;
     else if (k == "mem_free_bytes" || k == "mem_total_bytes") {
         int cur = -1;
         size_t fr = 0, tot = 0;
@@ -833,8 +930,16 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
     if (!plan) return FWA_OK;
     (void)hipSetDevice(plan->ctx->device);
     // work of this plan may still be in flight on the caller's stream; the pooled ring must not be handed to the
-    // next plan before it has drained (hipFree would have synchronised implicitly)
-    if (plan->frozen && plan->ring) (void)hipDeviceSynchronize();
+    // next plan before it has drained (hipFree would have synchronised implicitly).  Only THIS plan's last exec is
+    // waited for -- other streams and contexts keep running (a device-wide synchronise here stalled them all and is
+    // illegal while any stream captures a graph).  An exec that was captured into a graph records nothing real: the
+    // plan must outlive the graphs that replay it.
+    if (plan->ev_last) {
+        if (plan->frozen && plan->ring) (void)hipEventSynchronize(plan->ev_last);
+        (void)hipEventDestroy(plan->ev_last);
+    } else if (plan->frozen && plan->ring) {
+        (void)hipDeviceSynchronize();  // persistent-launch paths (no per-exec event)
+    }
     Pipeline pl = take_pipeline(plan);
     destroy_pipeline_objects(plan->ctx, pl, true);
     if (plan->ring_ctl) (void)hipFree(plan->ring_ctl);
@@ -889,7 +994,11 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return done();
     }
 
-    p->path = choose_path(fft_len, p->batch, p->lf);
+    {
+        bool cw = false;
+        p->path = choose_path(fft_len, p->batch, p->lf, &cw);
+        p->colsw = cw;
+    }
 
     // Forward/Inverse own their ping-pong partner (processor.rs:34-41,261-269).  It is only
     // materialised when the result must land there (odd log2 n) or the path ping-pongs.
@@ -1015,7 +1124,14 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
                 ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
                 hipError_t le;
-                if (plan->lf[0] > 10)
+                // k_colsw writes the slab tile-contiguously when the last pass (k_rows32) can read that layout back
+                const bool use_colsw = plan->colsw && fwa::colsw_supported(plan->lf[0]) && plan->lg <= 28;
+                const uint32_t ring_cw = (use_colsw && plan->tile_ring && !three && fwa::rows32_ring_supported(plan->lf[1], fwa::colsw_width(plan->lf[0])))
+                                             ? fwa::colsw_width(plan->lf[0]) : 0u;
+                if (use_colsw)
+                    le = fwa::launch_colsw(dir, plan->lf[0], true, ring_cw != 0, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1),
+                                           N, N, (uint32_t)cnt, ta.xcd_swizzle, s);
+                else if (plan->lf[0] > 10)
                     le = fwa::launch_cols32(dir, plan->lf[0], true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N,
                                             N, (uint32_t)cnt, ta.xcd_swizzle, s);
                 else if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
@@ -1035,9 +1151,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                     if (le != hipSuccess) return le;
                 }
                 // pass C: rows of the last axis, cw adjacent k1 per tile
-                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1]) && (plan->rows32 || plan->lf[1] > 10))
+                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1]) && (plan->rows32 || plan->lf[1] > 10 || ring_cw))
                     return fwa::launch_rows32(dir, plan->lf[1], slab, out + g * G * N, tb.tw_l[1], (uint32_t)N1, N, N, (uint32_t)cnt,
-                                              scale, ta.xcd_swizzle, s);
+                                              scale, ta.xcd_swizzle, ring_cw, s);
                 const uint32_t li = three ? 2 : 1;
                 cw = pass_cw(plan, li);
                 ta.in = slab; ta.out = out + g * G * N; ta.tw = tb.tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
@@ -1095,6 +1211,8 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "small_reg") *value = plan->small_reg;
     else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "rows32") *value = plan->rows32;
+    else if (k == "colsw") *value = plan->colsw;
+    else if (k == "tile_ring") *value = plan->tile_ring;
     else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
     else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
@@ -1123,7 +1241,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "group" || k == "streams") {
         if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths (2^20 two-pass, tiled)");
-        if (value < 1 || value > 4096) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (value < 1 || value > (k == "streams" ? 16 : 4096)) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         return build_pipeline(plan, k == "group" ? value : plan->group, k == "streams" ? value : plan->n_streams);
     }
     if (k == "tile_w") {
@@ -1177,9 +1295,9 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (st) { plan->path = old_path; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
         return st;
     }
-    if (k == "p1_gen" || k == "rows32") {
+    if (k == "p1_gen" || k == "rows32" || k == "colsw" || k == "tile_ring") {
         if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to tiled plans");
-        (k == "p1_gen" ? plan->p1_gen : plan->rows32) = value != 0;
+        (k == "p1_gen" ? plan->p1_gen : k == "rows32" ? plan->rows32 : k == "colsw" ? plan->colsw : plan->tile_ring) = value != 0;
         return FWA_OK;
     }
     if (k == "small_reg") {
@@ -1209,7 +1327,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
             plan->path = value;
             if (value == PATH_TEAM) { plan->lf[0] = plan->lg / 2; plan->lf[1] = plan->lg - plan->lf[0]; plan->lf[2] = 0; }
-            else (void)choose_path(plan->n, plan->batch, plan->lf);
+            else { bool cw = false; (void)choose_path(plan->n, plan->batch, plan->lf, &cw); plan->colsw = cw; }
             const int32_t st = setup_path(plan);
             if (st) { plan->path = old; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
             if (!st && value == PATH_TILED && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }

@@ -2,6 +2,16 @@
 #pragma once
 #include "kernels.h"
 
+// Diagnostic hooks: empty in the library.  tools/phase_probe.hip defines them before including a kernel source to
+// record in-kernel time stamps (cdna_hip_programming.md section 7, "In-kernel stamps": a separate diagnostic build, the
+// stamps go to a buffer of their own).
+#ifndef FWA_STAMP
+#define FWA_STAMP(slot)
+#endif
+#ifndef FWA_ENTRY_HOOK
+#define FWA_ENTRY_HOOK()
+#endif
+
 namespace fwa {
 
 // Buffer (SRD) addressing: one 32-bit per-lane byte offset + a scalar offset per access, so the 32 loads

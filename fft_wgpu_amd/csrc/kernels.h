@@ -24,8 +24,19 @@ hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint
 // per thread, transposed store out[k1 + n1*k2] (kernels_rows32.hip: k_rows32); tw = half table of W_{2^lg_l}
 bool rows32_supported(uint32_t lg_l);
 hipError_t prepare_rows32(uint32_t lg_l);
+bool rows32_ring_supported(uint32_t lg_l, uint32_t in_cw);
+// in_cw = 0: `in` is the n1 x 2^lg_l matrix; in_cw = 32 / 64: the tile-contiguous ring written by k_colsw
 hipError_t launch_rows32(int dir, uint32_t lg_l, const v2f *in, v2f *out, const v2f *tw, uint32_t n1, uint64_t in_sb,
-                         uint64_t out_sb, uint32_t n_transforms, float scale, uint32_t xcd_swizzle, hipStream_t st);
+                         uint64_t out_sb, uint32_t n_transforms, float scale, uint32_t xcd_swizzle, uint32_t in_cw,
+                         hipStream_t st);
+// pass A with short columns and wide tiles (lg_l = 9: 512 rows x 32 columns, lg_l = 8: 256 x 64; 512 threads, two
+// workgroups per CU; kernels_rows32.hip: k_colsw); tile_ring: tile-contiguous output [tile][k1][width]
+bool colsw_supported(uint32_t lg_l);
+uint32_t colsw_width(uint32_t lg_l);
+hipError_t prepare_colsw(uint32_t lg_l);
+hipError_t launch_colsw(int dir, uint32_t lg_l, bool out_is_ring, bool tile_ring, const v2f *in, v2f *out, const v2f *tw,
+                        const v2f *tw_lo, const v2f *tw_hi, uint32_t pitch, uint64_t in_sb, uint64_t out_sb,
+                        uint32_t n_transforms, uint32_t xcd_swizzle, hipStream_t st);
 // pass A with a 2048-point first factor (lg_l = 11, n = 2048 * pitch <= 2^28): 16 adjacent columns
 // per workgroup, matrix layout out, four-step twiddle of domain n (kernels_rows32.hip: k_cols32); tw = half table of W_{2^lg_l}
 bool cols32_supported(uint32_t lg_l);
@@ -92,5 +103,7 @@ hipError_t launch_ring_1m(int dir, const v2f *src, v2f *dst, v2f *ring, const v2
 hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);
+// `blocks` one-wave workgroups that spin for ticks x 10 ns (<= 1 ms) without touching memory
+hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st);
 
 }  // namespace fwa

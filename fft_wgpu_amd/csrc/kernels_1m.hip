@@ -69,10 +69,13 @@ __device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, 
     const uint32_t soff = tile * (W * 8);
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(in), rout = make_rsrc(out);
     v2f x[32];
+    FWA_ENTRY_HOOK();
+    FWA_STAMP(0);
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         x[j] = buf_load<AUX_NT>(rin, voff, soff + j * 262144);
     });
+    FWA_STAMP(1);
     reinterpret_cast<v4f *>(two)[tid] = reinterpret_cast<const v4f *>(tw_outer_tile)[tid];
     __syncthreads();
 
@@ -110,6 +113,7 @@ __device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, 
         const v2f w = cmul(A, two[32 * W + k2 * W + c]);
         buf_store<AUX_SC1>(cmul_tw<DIR>(x[brev<32>(k2)], w), rout, voff_o, soff_o + k2 * (32 * W * 8));
     });
+    FWA_STAMP(3);
 }
 
 // One pass-2 tile: row FFTs + transposed store.  `in` = ring slab of the transform, `out` = its 1024x1024
@@ -129,10 +133,13 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
     const uint32_t soff_in = tile * (W * W * 8);
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(in), rout = make_rsrc(out);
     v2f x[32];
+    FWA_ENTRY_HOOK();
+    FWA_STAMP(0);
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         x[j] = buf_load<AUX_IN>(rin, voff_in, soff_in + j * 262144);
     });
+    FWA_STAMP(1);
     after_load();
 
     stage1_fft_twiddle<DIR>(x, twi, np);
@@ -170,6 +177,7 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
         constexpr int k2 = decltype(k_)::value;
         buf_store<AUX_NT>(x[brev<32>(k2)] * scale, rout, voff_out, soff_out + k2 * 262144);
     });
+    FWA_STAMP(3);
 }
 
 // XCD-aware block -> tile mapping (cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, so

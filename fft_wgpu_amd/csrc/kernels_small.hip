@@ -462,6 +462,20 @@ hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples,
     return hipGetLastError();
 }
 
+// A kernel that occupies `blocks` one-wave workgroups for `ticks` x 10 ns and touches no memory: used once per context
+// to check that the internal chain streams of the pipelined paths really run kernels side by side (api.cpp: chain_streams).
+__global__ __launch_bounds__(64) void k_spin(uint32_t ticks)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st)
+{
+    if (ticks > 100000u) ticks = 100000u;  // 1 ms at most: the grid always drains
+    hipLaunchKernelGGL(k_spin, dim3(blocks), dim3(64), 0, st, ticks);
+    return hipGetLastError();
+}
+
 // Calibration copy, shaped like the one-launch FFT kernels: one workgroup per contiguous 64-KiB chunk, every thread
 // issues its 16 non-temporal 16-byte loads before the first store (256 KiB in flight per CU at four workgroups).  A
 // plain grid-stride float4 copy reaches 4.7-5.0 TB/s on this part, this shape 6 TB/s and more (the 6.29 TB/s of

@@ -144,7 +144,9 @@ int32_t fwa_plan_destroy(fwa_plan *plan);
 /* Pure host logic, no device needed: which path and factorisation a plan of length fft_len uses (for a batch
  * of at least 4 transforms; at n = 2^20 smaller batches take the tiled path, see "factors").
  * *path as in fwa_plan_get_i64("path"); log2_factors[0..2] = log2 of the per-pass FFT lengths
- * (0 = unused), e.g. 2^20 -> {10,10,0}, 2^24 -> {8,8,8}, 512 -> {9,0,0}. */
+ * (0 = unused), e.g. 2^20 -> {10,10,0}, 2^24 -> {9,7,8}, 2^18 -> {8,10,0}, 512 -> {9,0,0}.  The answer is the
+ * many-transform (throughput) regime; a plan over few transforms may pick smaller tiles: fwa_plan_get_i64("factors") on
+ * the plan is authoritative. */
 int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors[3]);
 
 /* Introspection / tuning (no reference analogue).  No key changes what a plan computes: every path and geometry

@@ -103,9 +103,9 @@ def test_path_selection_host_logic():
     for lg in range(1, 16):
         assert fw.describe_path(1 << lg) == (0, [1 << lg])      # one-launch kernels up to 32768
     assert fw.describe_path(1 << 20) == (1, [1024, 1024])       # headline two-pass pipeline
-    assert fw.describe_path(1 << 24) == (7, [1024, 128, 128])   # config C5: 1024-point first pass (k_p1_gen)
-    assert fw.describe_path(1 << 16) == (7, [1024, 64])
-    assert fw.describe_path(1 << 19) == (7, [1024, 512])
+    assert fw.describe_path(1 << 24) == (7, [512, 128, 256])    # config C5: 512 x 32-column first pass (k_colsw)
+    assert fw.describe_path(1 << 16) == (7, [256, 256])         # 256 x 64-column first pass (k_colsw)
+    assert fw.describe_path(1 << 19) == (7, [512, 1024])
     assert fw.describe_path(1 << 22) == (7, [1024, 4096])       # two passes: k_p1_gen + k_rows32 (4096-point rows)
     assert fw.describe_path(1 << 23) == (7, [2048, 4096])       # two passes: k_cols32 + k_rows32
     assert fw.describe_path(1 << 30) == (7, [1024, 1024, 1024])

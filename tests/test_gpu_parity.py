@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import REF_ABS_TOL, REL_TOL
+from fft_wgpu_amd.processor import PLAN_KEYS
 
 pytestmark = pytest.mark.gpu
 
@@ -50,10 +51,10 @@ def _run(fw, dev, queue, kind, x, n, **tunables):
     plan = {"Forward": lambda: fw.Forward(dev, queue, src, n),
             "Inverse": lambda: fw.Inverse(dev, queue, src, n),
             "Onlyinverse": lambda: fw.Onlyinverse(dev, queue, src, src2, n)}[kind]()
-    for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"):  # factors before group: it resets it
+    for key in PLAN_KEYS:  # factors before group: it resets it
         if tunables.get(key) is not None:
             plan.set(key, tunables[key])
-    assert not set(tunables) - {"path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"}
+    assert not set(tunables) - set(PLAN_KEYS)
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     queue.submit(enc.finish())
@@ -313,7 +314,7 @@ def test_team_pipeline_l2_resident(gpu, oracle, lg, batch, max_teams):
     n = 1 << lg
     x = oracle.gen_input(n, batch, first_transform=lg)
     f0 = lg // 2
-    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8), rows32=0)  # same tile arithmetic
+    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8), rows32=0, colsw=0)  # same tile arithmetic
     _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
     for rep in range(2):
         y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=8, max_teams=max_teams)
@@ -397,6 +398,36 @@ def test_first_pass_2048_column_kernel(gpu, oracle, lg, factors, batch):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
+@pytest.mark.parametrize("lg,factors,batch,tile_ring", [(20, (9, 11, 0), 5, 1), (20, (9, 11, 0), 3, 0), (20, (8, 12, 0), 3, 1),
+                                                        (20, (8, 12, 0), 2, 0), (19, (9, 10, 0), 5, 1), (19, (8, 11, 0), 3, 1),
+                                                        (18, (9, 9, 0), 7, 1), (18, (8, 10, 0), 5, 1), (17, (9, 8, 0), 9, 1),
+                                                        (16, (8, 8, 0), 9, 1), (21, (9, 12, 0), 3, 1), (24, (9, 7, 8), 1, 1),
+                                                        (26, (8, 9, 9), 1, 1)])
+def test_first_pass_short_wide_column_kernel(gpu, oracle, lg, factors, batch, tile_ring):
+    """Key "colsw": k_colsw as pass A -- 512-row x 32-column or 256-row x 64-column tiles (256- / 512-byte HBM segments, 512
+    threads, two workgroups per CU) -- with the tile-contiguous ring read back by k_rows32 ("tile_ring" = 1, where the
+    last pass supports it) or the matrix layout.  Forward and inverse against the f64 DFT (up to 2^24; the default plan
+    above), ragged groups and both chains; bit-identical between the two ring layouts."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    packed = factors[0] | (factors[1] << 8) | (factors[2] << 16)
+    extra = dict(group=2, streams=2) if batch > 2 else {}
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n, factors=packed, colsw=1, tile_ring=tile_ring, **extra)
+    assert plan.get("path") == 7 and plan.get("factors") == packed and plan.get("colsw") == 1 and which == lg % 2
+    if lg <= 24:
+        _check(oracle, y, oracle.dft_f64(x, n, -1), n)
+    else:
+        y0, _, _ = _run(fw, dev, queue, "Forward", x, n)
+        mx, l2 = oracle.compare(y, y0.astype(np.complex128))
+        assert mx <= 2e-6 and l2 <= 1e-6, (lg, mx, l2)
+    if tile_ring:
+        y_m, _, _ = _run(fw, dev, queue, "Forward", x, n, factors=packed, colsw=1, tile_ring=0, **extra)
+        assert np.array_equal(y.view(np.uint32), y_m.view(np.uint32))
+    z, _, _ = _run(fw, dev, queue, "Inverse", y, n, factors=packed, colsw=1, tile_ring=tile_ring, **extra)
+    _check(oracle, z, x.astype(np.complex128), n)
+
+
 @pytest.mark.parametrize("lg,factors,batch", [(19, (10, 9, 0), 5), (20, (10, 10, 0), 3), (21, (10, 11, 0), 3), (18, (9, 9, 0), 7),
                                               (22, (10, 12, 0), 3), (23, (11, 12, 0), 2), (18, (6, 12, 0), 9),
                                               (17, (6, 11, 0), 9), (20, (9, 11, 0), 2)])
@@ -423,19 +454,22 @@ def test_last_pass_rows32_kernel(gpu, oracle, lg, factors, batch):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
-@pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (10, 6, 0)), (17, 8, (8, 9, 0)),
-                                              (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (10, 8, 0)), (19, 2, (6, 6, 7)),
-                                              (19, 3, (10, 9, 0)), (20, 3, (6, 6, 8)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
-                                              (22, 1, (7, 7, 8)), (22, 2, (10, 12, 0)), (23, 1, (11, 12, 0)), (24, 1, (10, 7, 7))])
+@pytest.mark.parametrize("lg,batch,factors", [(16, 1, (8, 8, 0)), (16, 16, (8, 8, 0)), (16, 17, (8, 8, 0)), (17, 8, (8, 9, 0)),
+                                              (17, 9, (8, 9, 0)), (18, 1, (6, 6, 6)), (18, 4, (6, 6, 6)), (18, 5, (8, 10, 0)), (19, 2, (6, 6, 7)),
+                                              (19, 3, (9, 10, 0)), (20, 3, (6, 6, 8)), (21, 1, (7, 7, 7)), (21, 2, (10, 11, 0)),
+                                              (22, 1, (7, 7, 8)), (22, 2, (10, 12, 0)), (23, 1, (11, 12, 0)), (24, 1, (9, 7, 8))])
 def test_plan_picks_small_tiles_for_few_transforms(gpu, oracle, lg, batch, factors):
     """Latency regime (at most 2^20 samples per exec, a single 2^21, fewer than 4 of 2^20): balanced small tiles so that
-    every CU gets work; above it the 1024-point first pass.  Either way the transform is the same."""
+    every CU gets work (k_tile, "colsw" = 0); above it fat 16 Ki-point first-pass tiles (k_colsw up to 2^19 and from 2^24,
+    the 1024-point column kernels between).  Either way the transform is the same."""
     fw, dev, queue = gpu
     n = 1 << lg
     x = oracle.gen_input(n, batch, first_transform=100 + lg)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n)
     assert plan.get("path") == 7 and which == lg % 2
     assert plan.get("factors") == factors[0] | (factors[1] << 8) | (factors[2] << 16)
+    few = (lg < 20 and batch <= (1 << 20 >> lg)) or (lg in (21, 22) and batch == 1) or (lg == 20 and batch < 4)
+    assert plan.get("colsw") == (0 if few else int(lg <= 19 or lg >= 24))
     _check(oracle, y, oracle.dft_f64(x, n, -1), n)
 
 
@@ -682,7 +716,7 @@ def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):
     _check(oracle, y, oracle.dft_f64(x, 512, -1), 512)
 
 
-@pytest.mark.parametrize("lg,p1_gen", [(27, 1), (28, 1), (29, 1), (29, 0), (30, 1)])
+@pytest.mark.parametrize("lg,p1_gen", [(27, 1), (28, 1), (28, 10), (29, 1), (29, 0), (30, 1)])
 def test_large_single_transform_properties(gpu, lg, p1_gen):
     """n = 2^27 .. 2^30 (1 - 8 GiB per transform, three passes, 64-bit offsets inside ONE transform; from 2^29 a tile
     spans >= 4 GiB: k_p1_gen addresses a transform through four descriptors, k_tile (p1_gen = 0 for pass A, always for
@@ -700,8 +734,13 @@ def test_large_single_transform_properties(gpu, lg, p1_gen):
         queue.write_buffer(src, off * 8, zeros)
     queue.write_buffer(src, p * 8, np.ones(1, dtype=np.complex64))
     plan = fw.Forward(dev, queue, src, n)
+    if p1_gen == 10:  # the 1024-point first pass (k_p1_gen) at a size whose default is the 512 x 32 tile of k_colsw
+        plan.set("factors", 10 | (9 << 8) | (9 << 16))
+        p1_gen = 1
     plan.set("p1_gen", p1_gen)
-    assert plan.get("path") == 7 and plan.get("factors") >> 16 != 0 and plan.get("factors") & 255 == 10
+    first = plan.get("factors") & 255
+    assert plan.get("path") == 7 and plan.get("factors") >> 16 != 0
+    assert (first, plan.get("colsw")) == ((9, 1) if lg <= 28 and first != 10 else (10, 0 if lg > 28 else plan.get("colsw")))
     enc = dev.create_command_encoder()
     out = plan.proc(enc)
     enc.synchronize()

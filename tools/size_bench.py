@@ -14,16 +14,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lg-min", type=int, default=1)
     ap.add_argument("--lg-max", type=int, default=24)
+    ap.add_argument("--total-lg", type=int, default=28, help="log2 of the samples per size (28 = 2 GiB, 32 = C3's 32 GiB)")
+    ap.add_argument("--no-latency-shapes", action="store_true")
+    ap.add_argument("--set", default="", help="plan setting applied to every size (tools/sweep.py syntax)")
     args = ap.parse_args()
+    from sweep import parse_setting
+    kv = parse_setting(args.set)
     dev, queue = fw.prepare_gpu(0)
     enc = dev.create_command_encoder()
-    total_lg = 28
-    cases = [(lg, 1 << max(0, total_lg - lg)) for lg in range(args.lg_min, args.lg_max + 1)] + [(20, 1), (24, 1), (10, 1)]
+    total_lg = args.total_lg
+    cases = [(lg, 1 << max(0, total_lg - lg)) for lg in range(args.lg_min, args.lg_max + 1)]
+    if not args.no_latency_shapes:
+        cases += [(20, 1), (24, 1), (10, 1)]
     buf = dev.create_buffer(8 << max(total_lg, args.lg_max))
     for lg, batch in cases:
         n = 1 << lg
         view = dev.wrap_buffer(buf.device_ptr, n * batch * 8)
         plan = fw.Forward(dev, queue, view, n)
+        for key, val in kv.items():
+            plan.set(key, val)
         reps = 5 if n * batch >= (1 << 24) else 50
         times = []
         for r in range(reps + 1):
@@ -35,8 +44,8 @@ def main():
             if r:
                 times.append(a.elapsed_ms(b))
         ms = sorted(times)[len(times) // 2]
-        print(json.dumps({"lg_n": lg, "batch": batch, "path": plan.get("path"), "factors": plan.get("factors"), "launches": plan.get("launches_per_exec"),
-                          "ms": round(ms, 4), "Gsamples_s": round(n * batch / ms / 1e6, 2),
+        print(json.dumps({"lg_n": lg, "batch": batch, "footprint_GiB": round(n * batch * 8 / 2 ** 30, 3), "path": plan.get("path"), "factors": plan.get("factors"), "launches": plan.get("launches_per_exec"),
+                          "ms": round(ms, 4), "ms_all": [round(t, 3) for t in times], "Gsamples_s": round(n * batch / ms / 1e6, 2),
                           "roofline_frac": round(16 * n * batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
         plan.destroy()
 

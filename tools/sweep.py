@@ -15,6 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fft_wgpu_amd as fw  # noqa: E402
+from fft_wgpu_amd.processor import PLAN_KEYS  # noqa: E402
 
 
 def parse_setting(s):
@@ -68,7 +69,7 @@ def main():
     for s in settings:
         plan = fw.Forward(dev, queue, buf, n)
         kv = parse_setting(s)
-        for key in ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32"):
+        for key in PLAN_KEYS:
             if key in kv:
                 plan.set(key, kv[key])
         plans.append((s, plan, []))
