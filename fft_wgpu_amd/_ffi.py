@@ -8,6 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfft_wgpu_amd.so")
+# The laboratory build (`make -C fft_wgpu_amd/csrc lab`): the product library plus the kernel families that measured
+# slower than the defaults (persistent 2^20 ring, L2 teams, 1024-thread 2^20 tiles, LDS radix-2, direct 16-point kernels,
+# the wavefront-shuffle exchange).  Same ABI; only tools/ and the bit-identity tests load it (Device(lab=True)).
+LAB_LIB_PATH = os.path.join(_HERE, "libfft_wgpu_amd_lab.so")
 
 FWA_OK = 0
 FORWARD, INVERSE_SCALED, INVERSE_UNSCALED, NORMALIZE = 0, 1, 2, 3
@@ -73,27 +77,27 @@ _SIGNATURES = {
     "fwa_calib_copy": (_I32, [_P, _P, _U64, _P]),
 }
 
-_lib = None
+_libs = {}
 
 
-def lib():
+def lib(lab=False):
     """Load the shared library (once).  Raises if it was not built: no CPU fallback exists."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    path = LAB_LIB_PATH if lab else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C fft_wgpu_amd/csrc`.  fft_wgpu_amd has no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C fft_wgpu_amd/csrc{' lab' if lab else ''}`.  fft_wgpu_amd has no CPU fallback.")
+        L = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here = header/library mismatch
             f.restype = res
             f.argtypes = args
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
-def check(status, ctx_handle, where):
+def check(status, ctx_handle, where, L=None):
     if status != FWA_OK:
-        msg = lib().fwa_last_error_string(ctx_handle)
+        msg = (L or lib()).fwa_last_error_string(ctx_handle)
         raise FwaError(status, msg.decode() if msg else "", where)

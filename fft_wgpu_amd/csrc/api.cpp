@@ -25,6 +25,14 @@
 
 using fwa::v2f;
 
+// FWA_LAB (libfft_wgpu_amd_lab.so, `make lab`): the same ABI plus the kernel families that measured slower than the
+// shipped ones -- paths 5 and 8, tile_w = 32, small_reg != 1.  The product library rejects those settings.
+#ifdef FWA_LAB
+constexpr bool kLab = true;
+#else
+constexpr bool kLab = false;
+#endif
+
 enum fwa_path : int64_t {
     PATH_SMALL = 0,       // n <= 32768: one launch (k_tiny / k_small16 / k_lds_small)
     PATH_TWOPASS_1M = 1,  // n = 2^20: k_p1_1m + k_p2_1m per group of transforms
@@ -142,6 +150,9 @@ int32_t fail(const fwa_ctx *ctx, int32_t st, const std::string &msg)
 }
 int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t st = FWA_ERR_HIP)
 {
+    // HIP keeps the last error until somebody reads it; the launch wrappers read it after every launch, so an error that
+    // has been reported here (e.g. an out-of-memory hipMalloc) must not surface again as a bogus launch failure later
+    (void)hipGetLastError();
     std::string m = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     if (e == hipErrorOutOfMemory) st = FWA_ERR_OUT_OF_MEMORY;
     return fail(ctx, st, m);
@@ -255,7 +266,7 @@ int32_t build_tables(fwa_ctx *ctx, uint32_t n, int64_t path, const uint32_t lf[3
             for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
         st = upload_table(ctx, inner, &t->tw_inner);
         const uint64_t N = 1ull << 20;
-        for (int wi = 0; wi < 2 && !st; ++wi) {
+        for (int wi = 0; wi < (kLab ? 2 : 1) && !st; ++wi) {
             const uint32_t W = wi ? 32 : 16, tiles = 1024 / W;
             std::vector<v2f> outer((size_t)tiles * 64 * W);
             for (uint32_t tile = 0; tile < tiles; ++tile)
@@ -419,6 +430,7 @@ Pipeline take_pipeline(fwa_plan *p)
 int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
 {
     fwa_ctx *ctx = p->ctx;
+#ifdef FWA_LAB
     if (p->path == PATH_RING_1M) {
         // one launch, no internal streams: ring of min(ring_slots, batch) transforms + the control words
         Pipeline pl;
@@ -469,6 +481,7 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
         p->ring = pl.ring; p->ring_bytes = pl.ring_bytes;
         return FWA_OK;
     }
+#endif
     if (p->path != PATH_TWOPASS_1M && p->path != PATH_TILED) return FWA_OK;
     if (group < 1) group = 1;
     if ((uint64_t)group > p->batch && p->batch) group = (int64_t)p->batch;
@@ -538,13 +551,18 @@ int32_t setup_path(fwa_plan *p)
     }
     if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M || (p->path == PATH_TILED && p->lf[0] == 10)) && !ctx->setup_1m_done) {
         hipError_t e = fwa::setup_1m_kernels();
+#ifdef FWA_LAB
+        if (e == hipSuccess) e = fwa::setup_lab_1m_kernels();
+#endif
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_1m_done = true;
     }
+#ifdef FWA_LAB
     if (p->path == PATH_TEAM) {
         hipError_t pe = fwa::prepare_team(p->lg);
         if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
     }
+#endif
     if (p->path == PATH_TILED) {
         const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i)
@@ -570,31 +588,48 @@ int32_t setup_path(fwa_plan *p)
     const uint32_t sig = p->lf[0] | (p->lf[1] << 8) | (p->lf[2] << 16);
     const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M
                                               : (p->path == PATH_TEAM ? (int64_t)PATH_TILED : p->path), sig);
+    // The tables of the NEW path / factorisation are held locally and handed to the plan only once its pipeline has
+    // been built: a failed re-tune (e.g. no memory for the new ring) leaves the plan with the tables of the factors it
+    // keeps (the callers restore path and factors).
+    std::shared_ptr<Tables> tb;
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
-        p->tb = it->second;
+        tb = it->second;
         ++ctx->n_table_hits;
     } else {
-        auto tb = std::make_shared<Tables>();
+        tb = std::make_shared<Tables>();
         int32_t st = build_tables(ctx, fft_len, std::get<1>(key), p->lf, tb.get());
         if (st) return st;
         ++ctx->n_table_builds;
-        p->tb = tb;
         ctx->tables.emplace(key, tb);
     }
+    int32_t st = FWA_OK;
     if (p->path == PATH_TILED) {
         // the intermediate of a group of transforms lives in a ring slab of 128 MiB per chain (two chains = the
         // 256-MiB Infinity Cache; group sweep in profiles/round1/h_tiled_group_sweep.jsonl)
         const uint64_t per = (uint64_t)fft_len * sizeof(v2f);
         int64_t g = (int64_t)((128ull << 20) / per);
         if (g < 1) g = 1;
-        return build_pipeline(p, g, default_chains(p->batch, g));
+        st = build_pipeline(p, g, default_chains(p->batch, g));
+    } else if (p->path == PATH_TWOPASS_1M) {
+        st = build_pipeline(p, 16, default_chains(p->batch, 16));  // 16 transforms = 1024 tiles per launch
+    } else if (p->path == PATH_RING_1M || p->path == PATH_TEAM) {
+        st = build_pipeline(p, 0, 0);
     }
-    if (p->path == PATH_TWOPASS_1M) {
-        return build_pipeline(p, 16, default_chains(p->batch, 16));  // 16 transforms = 1024 tiles per launch
-    }
-    if (p->path == PATH_RING_1M || p->path == PATH_TEAM) return build_pipeline(p, 0, 0);
+    if (st) return st;
+    p->tb = tb;
     return FWA_OK;
+}
+
+static size_t ctl_bytes(const fwa_plan *p)
+{
+#ifdef FWA_LAB
+    if (p->path == PATH_TEAM) return fwa::team_ctl_bytes(p->lg, (uint32_t)p->max_teams);
+    return fwa::ring_ctl_bytes(p->batch);
+#else
+    (void)p;
+    return 0;
+#endif
 }
 
 static fwa_buf *result_buffer(fwa_plan *p)
@@ -1059,16 +1094,23 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             if (scale != 1.0f) e = fwa::launch_scale(a, a, total, scale, st);
             break;
         case PATH_SMALL:
-            if (plan->small_reg == 1 && plan->n <= 256)
+#ifdef FWA_LAB
+            if (plan->small_reg != 1) {  // laboratory kernels (A/B): direct 16-point kernels, shuffle exchange, LDS radix 2
+                if (plan->small_reg && plan->n < 16)
+                    e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
+                else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
+                    e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
+                else if (plan->small_reg)
+                    e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
+                else
+                    e = fwa::launch_lds_small(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
+                break;
+            }
+#endif
+            if (plan->n <= 256)
                 e = fwa::launch_chunk(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
-            else if (plan->small_reg && plan->n < 16)
-                e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
-            else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
-                e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
-            else if (plan->small_reg)
-                e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
             else
-                e = fwa::launch_lds_small(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
+                e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
             break;
         case PATH_R2_GLOBAL: {
             const v2f *tw = plan->tw_half_private ? plan->tw_half_private : tb.tw_half;
@@ -1092,6 +1134,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale, swz, s);
             });
         }
+#ifdef FWA_LAB
         case PATH_RING_1M: {
             if (!plan->ring || !plan->ring_ctl) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
             const uint64_t slots = (uint64_t)plan->ring_slots < plan->batch ? (uint64_t)plan->ring_slots : plan->batch;
@@ -1106,6 +1149,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                                  (uint32_t)plan->batch, (uint32_t)plan->max_teams, (uint32_t)plan->wgs, scale, st);
             break;
         }
+#endif
         case PATH_TILED: {
             // n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3).  Per group of transforms:
             // pass A: FFT over n1 (cols, twiddle W_n), user buffer -> ring slab; [pass B: FFT over n2 per k1 (cols,
@@ -1217,7 +1261,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
         *value = (int64_t)plan->ring_bytes + (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
-                 (plan->ring_ctl ? (int64_t)fwa::ring_ctl_bytes(plan->batch) : 0);
+                 (plan->ring_ctl ? (int64_t)ctl_bytes(plan) : 0);
     else if (k == "launches_per_exec") {
         switch (plan->path) {
             case PATH_TWOPASS_1M: *value = 2 * ng; break;
@@ -1247,17 +1291,30 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "tile_w") {
         if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
         if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "tile_w is 16 or 32");
+        if (value == 32 && !kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "tile_w = 32 is a laboratory variant (libfft_wgpu_amd_lab.so)");
         plan->tile_w = value;
         return FWA_OK;
     }
+#ifdef FWA_LAB
     if (k == "max_teams" || (k == "wgs" && plan->path == PATH_TEAM)) {
         if (plan->path != PATH_TEAM) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the team path");
         if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
-        if (k == "wgs") { plan->wgs = value; return FWA_OK; }
+        if (k == "wgs") {
+            // a team only forms from workgroups of ONE XCD and blocks are dealt round-robin over the 8 XCDs: fewer than
+            // 8 x team size workgroups may leave every XCD short of a team and the launch would transform nothing
+            uint32_t ts = 0, th = 0;
+            size_t lds = 0;
+            fwa::team_geometry(plan->lg, &ts, &th, &lds);
+            if (value < 8 * (int64_t)ts) return fail(ctx, FWA_ERR_INVALID_ARG, "wgs must be at least 8 x the team size");
+            plan->wgs = value;
+            return FWA_OK;
+        }
         plan->max_teams = value;
         return build_pipeline(plan, 0, 0);
     }
-    if (k == "depth" || k == "ring_slots" || k == "wgs") {
+#endif
+    if (k == "max_teams" || k == "depth" || k == "ring_slots" || k == "wgs") {
+        if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "key belongs to a laboratory path (libfft_wgpu_amd_lab.so)");
         if (plan->path != PATH_RING_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
         if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         if (k == "wgs") { plan->wgs = value; return FWA_OK; }
@@ -1301,7 +1358,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         return FWA_OK;
     }
     if (k == "small_reg") {
-        if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 16384");
+        if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 32768");
+        if (value != 1 && !kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "small_reg != 1 selects laboratory kernels (libfft_wgpu_amd_lab.so)");
         if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
         // 1: k_chunk (4 .. 256) and k_small32 (from 512), the default; 3: the direct-addressing kernels k_tiny16 /
         // k_small16 up to 4096 (A/B); 2: as 3 with the wavefront-shuffle exchange at n = 32/64/128; 0: LDS radix-2 kernel
@@ -1311,6 +1369,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "path") {
         if (plan->kind == FWA_NORMALIZE) return fail(ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
         if (value == plan->path) return FWA_OK;
+        if ((value == PATH_RING_1M || value == PATH_TEAM) && !kLab)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "paths 5 and 8 are laboratory paths (libfft_wgpu_amd_lab.so)");
         if ((value == PATH_RING_1M || value == PATH_TWOPASS_1M) && (plan->path == PATH_RING_1M || plan->path == PATH_TWOPASS_1M)) {
             // the two forms of the 2^20 pipeline: per-group launches with a large ring, or one persistent launch
             const int64_t old = plan->path;
@@ -1321,8 +1381,10 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             return st;
         }
         if ((value == PATH_TEAM || value == PATH_TILED) && (plan->path == PATH_TEAM || plan->path == PATH_TILED)) {
+#ifdef FWA_LAB
             if (value == PATH_TEAM && !fwa::team_supported(plan->lg))
                 return fail(ctx, FWA_ERR_UNSUPPORTED, "the team path covers n = 2^16 .. 2^18");
+#endif
             const int64_t old = plan->path;
             uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
             plan->path = value;

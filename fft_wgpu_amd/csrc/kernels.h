@@ -1,4 +1,4 @@
-// kernels.h -- launch wrappers implemented in kernels_{small,tiled,1m}.hip (internal to the library).
+// kernels.h -- launch wrappers implemented in kernels_*.hip (internal to the library).
 #pragma once
 #include "cplx.h"
 
@@ -6,13 +6,6 @@ namespace fwa {
 
 hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint32_t stage,
                            uint64_t batch, float scale, hipStream_t st);
-hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                            hipStream_t st);
-// 16 <= n <= 16384: register radix-16 Stockham (one launch); src == dst allowed (a transform is read
-// completely before any of it is written)
-// wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
-hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                          bool wave_shuffle, hipStream_t st);
 // 4 <= n <= 256: contiguous 32-KiB chunks per workgroup, linear global access, operands staged in LDS
 // (kernels_chunk.hip: k_chunk); in place allowed
 hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
@@ -68,18 +61,6 @@ struct TileArgs {
 bool tile_supported(uint32_t lg_l, uint32_t cw);
 hipError_t prepare_tile(uint32_t lg_l, uint32_t cw);
 hipError_t launch_tile(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
-// k_team (kernels_tiled.hip): both passes of an n = 2^16 .. 2^18 transform in one persistent launch, intermediate kept
-// in the L2 of one XCD.  slabs = 8 * max_teams * n elements; ctl = team_ctl_bytes() bytes (zeroed per launch; ctl[1] != 0
-// afterwards = a bounded spin timed out).
-bool team_supported(uint32_t lg_n);
-void team_geometry(uint32_t lg_n, uint32_t *team_size, uint32_t *threads, size_t *lds_bytes);
-size_t team_ctl_bytes(uint32_t lg_n, uint32_t max_teams);
-hipError_t prepare_team(uint32_t lg_n);
-hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *slabs, const v2f *tw_a, const v2f *tw_lo,
-                       const v2f *tw_hi, const v2f *tw_c, uint32_t *ctl, uint32_t batch, uint32_t max_teams,
-                       uint32_t n_workgroups, float scale, hipStream_t st);
-// n = 2, 4, 8: whole transforms per thread (in place allowed)
-hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
 hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();
 // One pass of the 2^20 pipeline over `n_transforms` transforms; transform i of the launch uses ring slot i.
@@ -94,16 +75,44 @@ hipError_t launch_p2_1m(int dir, int tile_w, const v2f *ring, v2f *dst, const v2
 hipError_t launch_p1_gen(int dir, bool out_is_ring, const v2f *src, v2f *dst, const v2f *tw_inner, const v2f *tw_lo,
                          const v2f *tw_hi, uint32_t pitch, uint64_t in_sb, uint64_t out_sb, uint32_t n_transforms,
                          uint32_t xcd_swizzle, hipStream_t st);
+hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
+hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
+hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);
+// `blocks` one-wave workgroups that spin for ticks x 10 ns (<= 1 ms) without touching memory
+hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st);
+
+#ifdef FWA_LAB
+// ---- laboratory build only (kernels_lab_*.hip): kernel families that measured slower than the shipped ones ----
+hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                            hipStream_t st);
+// 16 <= n <= 16384: register radix-16 Stockham (one launch); src == dst allowed (a transform is read
+// completely before any of it is written)
+// wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
+hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
+                          bool wave_shuffle, hipStream_t st);
+// k_team (kernels_tiled.hip): both passes of an n = 2^16 .. 2^18 transform in one persistent launch, intermediate kept
+// in the L2 of one XCD.  slabs = 8 * max_teams * n elements; ctl = team_ctl_bytes() bytes (zeroed per launch; ctl[1] != 0
+// afterwards = a bounded spin timed out).
+bool team_supported(uint32_t lg_n);
+void team_geometry(uint32_t lg_n, uint32_t *team_size, uint32_t *threads, size_t *lds_bytes);
+size_t team_ctl_bytes(uint32_t lg_n, uint32_t max_teams);
+hipError_t prepare_team(uint32_t lg_n);
+hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *slabs, const v2f *tw_a, const v2f *tw_lo,
+                       const v2f *tw_hi, const v2f *tw_c, uint32_t *ctl, uint32_t batch, uint32_t max_teams,
+                       uint32_t n_workgroups, float scale, hipStream_t st);
+// n = 2, 4, 8: whole transforms per thread (in place allowed)
+hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
 // Persistent form: one launch per exec, ring of `ring_slots` transforms (>= depth + 1); `ctl` = ring_ctl_bytes(batch)
 // bytes of device memory (zeroed here per call); ctl[1] != 0 afterwards means a bounded spin timed out.
 size_t ring_ctl_bytes(uint64_t batch);
 hipError_t launch_ring_1m(int dir, const v2f *src, v2f *dst, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                           uint32_t *ctl, uint32_t batch, uint32_t depth, uint32_t ring_slots, uint32_t n_workgroups,
                           float scale, hipStream_t st);
-hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st);
-hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples, float scale, hipStream_t st);
-hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st);
-// `blocks` one-wave workgroups that spin for ticks x 10 ns (<= 1 ms) without touching memory
-hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st);
+hipError_t setup_lab_1m_kernels();
+hipError_t launch_p1_1m_w32(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
+                            uint32_t n_transforms, uint32_t xcd_swizzle, hipStream_t st);
+hipError_t launch_p2_1m_w32(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms, float scale,
+                            uint32_t xcd_swizzle, hipStream_t st);
+#endif
 
 }  // namespace fwa

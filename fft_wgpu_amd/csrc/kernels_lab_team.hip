@@ -1,5 +1,5 @@
-// kernels_team.hip -- (4/4) k_team: both passes of a two-pass transform in one persistent launch, the intermediate kept
-// in the L2 of one XCD (opt-in path 8).
+// kernels_lab_team.hip -- LABORATORY build only (libfft_wgpu_amd_lab.so): k_team, both passes of a two-pass transform in one
+// persistent launch, the intermediate kept in the L2 of one XCD (path 8; measured no faster than the per-pass launches).
 #include "tile_body.h"
 
 namespace fwa {
@@ -204,7 +204,10 @@ hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *sl
     if (batch == 0) return hipSuccess;
     uint32_t ts, th; size_t lds;
     team_geometry(lg_n, &ts, &th, &lds);
-    if (!ts || max_teams == 0 || n_workgroups < ts) return hipErrorInvalidValue;
+    // A team forms from workgroups of ONE XCD; with at least 8 x team size workgroups some XCD receives a full team
+    // however the blocks are dealt (pigeonhole), and one team alone drains the whole batch.  Fewer could leave every XCD
+    // short of a team: every workgroup would give up and the launch would report success without transforming anything.
+    if (!ts || max_teams == 0 || n_workgroups < 8 * ts) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(ctl, 0, team_ctl_bytes(lg_n, max_teams), st);
     if (e != hipSuccess) return e;
     TeamArgs a{src, dst, slabs, tw_a, tw_lo, tw_hi, tw_c, ctl, batch, max_teams, scale};

@@ -24,9 +24,9 @@ class _Plan:
         self.buffer_b = src2
         self.fft_len = fft_len
         h = ctypes.c_void_p()
-        st = _ffi.lib().fwa_plan_create(device._h, self._kind, fft_len, src._h,
+        st = self.device._L.fwa_plan_create(device._h, self._kind, fft_len, src._h,
                                         src2._h if src2 is not None else None, ctypes.byref(h))
-        _ffi.check(st, device._h, f"fwa_plan_create({type(self).__name__})")
+        _ffi.check(st, device._h, f"fwa_plan_create({type(self).__name__})", self.device._L)
         self._h = h
         self._results = {}
 
@@ -37,8 +37,8 @@ class _Plan:
     def proc(self, encoder):
         """Enqueue the transform on ``encoder`` and return the buffer that will hold the result."""
         res = ctypes.c_void_p()
-        st = _ffi.lib().fwa_plan_exec(self._h, encoder._h if encoder is not None else None, ctypes.byref(res))
-        _ffi.check(st, self.device._h, "fwa_plan_exec")
+        st = self.device._L.fwa_plan_exec(self._h, encoder._h if encoder is not None else None, ctypes.byref(res))
+        _ffi.check(st, self.device._h, "fwa_plan_exec", self.device._L)
         for b in (self.buffer_a, self.buffer_b):
             if b is not None and b._h is not None and b._h.value == res.value:
                 return b
@@ -50,17 +50,17 @@ class _Plan:
 
     def get(self, key):
         v = ctypes.c_int64()
-        _ffi.check(_ffi.lib().fwa_plan_get_i64(self._h, key.encode(), ctypes.byref(v)), self.device._h,
-                   "fwa_plan_get_i64")
+        _ffi.check(self.device._L.fwa_plan_get_i64(self._h, key.encode(), ctypes.byref(v)), self.device._h,
+                   "fwa_plan_get_i64", self.device._L)
         return v.value
 
     def set(self, key, value):
-        _ffi.check(_ffi.lib().fwa_plan_set_i64(self._h, key.encode(), int(value)), self.device._h,
-                   "fwa_plan_set_i64")
+        _ffi.check(self.device._L.fwa_plan_set_i64(self._h, key.encode(), int(value)), self.device._h,
+                   "fwa_plan_set_i64", self.device._L)
 
     def destroy(self):
         if self._h:
-            _ffi.lib().fwa_plan_destroy(self._h)
+            self.device._L.fwa_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -155,24 +155,35 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "batch", "fft_len",
  *   "path": 0 one-launch kernels (n <= 32768), 1 two-pass 2^20 pipeline (one launch per pass and group of
  *           transforms), 2 literal radix-2 recurrence (one launch per stage, kernel/fft.wgsl:27-62; forced only),
- *           3 normalize, 4 identity (n = 1), 5 the 2^20 pipeline as ONE persistent launch with a small ring (opt-in),
+ *           3 normalize, 4 identity (n = 1),
  *           7 tiled pipeline: two passes at 2^16..2^19 and 2^21..2^23, three at 2^24..2^30 and at 2^20 with fewer than 4 transforms,
- *           8 both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2 (opt-in),
  *   "factors": log2(N1) | log2(N2) << 8 | log2(N3) << 16 of a multi-pass plan,
  *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's twiddle tables),
- *   "group" (transforms per launch), "streams" (internal streams the groups alternate over)      [paths 1, 7]
- *   "tile_w" (16 or 32 columns per tile), "xcd_swizzle" (XCD-aware block -> tile mapping, bit 0)   [paths 1, 7]
- *   "depth", "ring_slots", "wgs" (path 5), "max_teams", "wgs" (path 8),
+ *   "group" (transforms per launch), "streams" (chain streams the groups alternate over, <= 16)   [paths 1, 7]
+ *   "xcd_swizzle" (XCD-aware block -> tile mapping, bit 0)                                         [paths 1, 7]
+ *   "colsw" (tiled plans whose first factor is 256 / 512: 1 = k_colsw, 256 x 64 / 512 x 32 column tiles, as pass A -- the
+ *   default in the many-transform regime at 2^16..2^19 and 2^24..2^28 -- 0 = the generic tile kernel),
+ *   "tile_ring" (k_colsw followed by the row kernel: 1 = tile-contiguous ring slab (default), 0 = matrix layout),
  *   "p1_gen" (tiled plans whose first factor is 1024: 1 = the 2^20 pipeline's column kernel at run-time
  *   pitch as pass A (default), 0 = the generic tile kernel),
  *   "rows32" (two-pass tiled plans whose second factor is 512 .. 4096: 1 = 32-point-per-thread row kernel with the
- *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 and 4096 exist only in the former),
- *   "small_reg" (n <= 32768: 1 = default: linear 32-KiB chunks staged through LDS for n = 4 .. 256, 32 points per
- *           thread from 512; 3 = the direct-addressing 16-point kernels up to 4096 (A/B); 2 = wave-shuffle exchange at
- *           32/64/128; 0 = LDS radix-2 kernel up to 4096),
- *   "device_error" (paths 5, 8; synchronises the device; non-zero = a bounded in-kernel spin timed out).
- * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "tile_w", "xcd_swizzle", "factors",
- * "depth", "ring_slots", "max_teams", "wgs", "small_reg", "p1_gen", "rows32", "path" (2 anywhere; 1 <-> 5 at 2^20; 7 <-> 8 at 2^16..2^18). */
+ *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 and 4096 exist only in the former).
+ * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "xcd_swizzle", "factors", "colsw",
+ * "tile_ring", "p1_gen", "rows32", "path" (2 anywhere).
+ * fwa_ctx_get_i64: "device", "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "pooled_ring_bytes",
+ * "last_plan_create_us", "mem_free_bytes", "mem_total_bytes", "chain_streams" (chain streams created so far),
+ * "chain_checks" / "chain_rejects" (candidates tested / discarded because they did not overlap the other chains),
+ * "chain_single_us" / "chain_pair_us" (the check's spin kernel alone / on all chains at once).
+ *
+ * Laboratory build only (fft_wgpu_amd/libfft_wgpu_amd_lab.so, `make -C fft_wgpu_amd/csrc lab`; the product library
+ * answers FWA_ERR_UNSUPPORTED): kernel families that measured slower than the shipped ones, kept for A/B timing and
+ * bit-identity tests --
+ *   "path" 5 (the 2^20 pipeline as ONE persistent launch with a small ring; 1 <-> 5 at 2^20) with "depth", "ring_slots",
+ *   "wgs"; "path" 8 (both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2;
+ *   7 <-> 8) with "max_teams", "wgs" (>= 8 x team size); "device_error" (paths 5, 8; synchronises the device; non-zero
+ *   = a bounded in-kernel spin timed out); "tile_w" = 32 (2^20: 1024-thread workgroups, 256-byte segments);
+ *   "small_reg" (n <= 32768: 1 = the shipped kernels; 3 = the direct-addressing 16-point kernels up to 4096; 2 = + the
+ *   wavefront-shuffle exchange at 32 / 64 / 128; 0 = LDS radix-2 kernel up to 4096). */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 

@@ -25,7 +25,7 @@ def pytest_configure(config):
     import shutil
     import subprocess
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fft_wgpu_amd", "csrc"), "-j8"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fft_wgpu_amd", "csrc"), "-j8", "all", "lab"])
 
 
 @pytest.fixture(scope="session")

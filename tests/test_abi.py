@@ -27,6 +27,32 @@ def test_library_exports_every_declared_symbol():
     assert L.fwa_abi_version() == 2
 
 
+def test_laboratory_library_has_the_same_abi_and_the_product_has_no_laboratory_kernels():
+    """the slower kernel families live in libfft_wgpu_amd_lab.so only.  Same exported ABI; the
+    product library's device code contains none of the laboratory kernels."""
+    import subprocess
+    from fft_wgpu_amd import _ffi
+    lab = _ffi.lib(lab=True)
+    for name in _header_functions():
+        assert hasattr(lab, name), f"{name} missing from the laboratory library"
+    assert lab.fwa_abi_version() == _ffi.lib().fwa_abi_version()
+    lab_kernels = (b"k_ring_1m", b"k_team", b"k_lds_small", b"k_tiny16", b"k_small16", b"k_tiny2")
+    prod = open(_ffi.LIB_PATH, "rb").read()
+    labb = open(_ffi.LAB_LIB_PATH, "rb").read()
+    for k in lab_kernels:
+        assert k not in prod, f"{k!r} found in the product library"
+        assert k in labb, f"{k!r} missing from the laboratory library"
+    # the 1024-thread form of the 2^20 tiles (tile_w = 32) is a laboratory instantiation too
+    assert b"k_p1_1mILin1ELi32E" not in prod and b"k_p1_1mILin1ELi32E" in labb
+    assert b"k_p1_1mILin1ELi16E" in prod and b"k_colsw" in prod and b"k_rows32" in prod
+    # only tools/ and the laboratory tests ask for the laboratory build
+    hits = subprocess.run(["grep", "-rlE", r"lab=True|lab=args\.lab|LAB_LIB_PATH", "--include=*.py", ROOT],
+                          capture_output=True, text=True).stdout.split()
+    rel = sorted(os.path.relpath(h, ROOT) for h in hits)
+    assert all(r.startswith(("tools/", "tests/")) or r in ("fft_wgpu_amd/_ffi.py", "fft_wgpu_amd/device.py") for r in rel), rel
+    assert not any(r in ("bench.py", "__graft_entry__.py") for r in rel)
+
+
 def test_rust_shim_declares_exactly_the_header_symbols():
     """rust_shim/ cannot be compiled here (no rustc): at least its `extern "C"` block must name exactly the functions
     include/fft_wgpu_amd.h declares, and its plans must keep the reference's public signatures."""

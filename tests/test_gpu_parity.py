@@ -98,12 +98,10 @@ def test_reference_known_answers(gpu, known_answers):
         assert which == int(np.log2(n)) % 2    # processor.rs:153-157
 
 
-# ---- K4: numpy float64 fixtures, every power of two 2..1024: register kernels (default: 16 points per thread up to
-# 256, 32 points per thread from 512), the 16-point kernel at every size (small_reg=3), LDS radix-2 kernel
-# (small_reg=0), the wavefront-shuffle exchange at n = 32/64/128 (small_reg=2) and the literal one-launch-per-stage
-# recurrence (path=2) ----
-@pytest.mark.parametrize("path,small_reg", [(None, 1), (None, 2), (None, 3), (None, 0), (2, None)])
-def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
+# ---- K4: numpy float64 fixtures, every power of two 2..1024: the shipped kernels (k_chunk up to 256, k_small32 from 512)
+# and the literal one-launch-per-stage recurrence (path=2); the laboratory kernels (small_reg = 0, 2, 3) run the same
+# body in tests/test_gpu_lab.py ----
+def _fixture_sizes_body(gpu, oracle, k4, path, small_reg):
     fw, dev, queue = gpu
     for lg in range(1, 11):
         n = 1 << lg
@@ -115,6 +113,11 @@ def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
         _check(oracle, y, k4[f"inv_unscaled_{n}"], n)
         y, _, _ = _run(fw, dev, queue, "Inverse", x, n, path=path, small_reg=small_reg)
         _check(oracle, y, k4[f"inv_unscaled_{n}"] / n, n)
+
+
+@pytest.mark.parametrize("path,small_reg", [(None, 1), (2, None)])
+def test_fixture_sizes(gpu, oracle, k4, path, small_reg):
+    _fixture_sizes_body(gpu, oracle, k4, path, small_reg)
 
 
 def test_literal_recurrence_matches_restatement_bitwise_shape(gpu, oracle):
@@ -159,9 +162,7 @@ def test_config_c1_n1024_batch1(gpu, oracle):
 
 # the 2^20 two-pass pipeline: (batch, group, streams, tile width); batches below 4 take the tiled path unless
 # the plan is re-tuned, so C2 (batch 1) is checked on both
-@pytest.mark.parametrize("batch,group,streams,tile_w", [(4, 8, 2, 32), (5, 2, 1, 32), (17, 4, 3, 32), (23, 3, 2, 32),
-                                                         (4, 8, 2, 16), (5, 2, 1, 16), (17, 4, 3, 16), (9, 16, 2, 16)])
-def test_config_c2_n1m(gpu, oracle, batch, group, streams, tile_w):
+def _c2_n1m_body(gpu, oracle, batch, group, streams, tile_w):
     fw, dev, queue = gpu
     n = 1 << 20
     x = oracle.gen_input(n, batch)
@@ -180,6 +181,11 @@ def test_config_c2_n1m(gpu, oracle, batch, group, streams, tile_w):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
+@pytest.mark.parametrize("batch,group,streams,tile_w", [(4, 8, 2, 16), (5, 2, 1, 16), (17, 4, 3, 16), (9, 16, 2, 16), (23, 3, 2, 16)])
+def test_config_c2_n1m(gpu, oracle, batch, group, streams, tile_w):
+    _c2_n1m_body(gpu, oracle, batch, group, streams, tile_w)
+
+
 def test_config_c2_n1m_batch1(gpu, oracle):
     """BASELINE config C2: one 2^20 transform.  Too few tiles for the two-pass pipeline: the plan takes the
     three-pass tiled form (64 x 64 x 256); the result must match the pipeline's to rounding."""
@@ -194,7 +200,13 @@ def test_config_c2_n1m_batch1(gpu, oracle):
     _check(oracle, z, x.astype(np.complex128), n)
 
 
-def test_n1m_pipeline_geometries_are_bit_identical(gpu, oracle):
+GEOMETRIES_16 = (dict(tile_w=16), dict(tile_w=16, xcd_swizzle=0), dict(tile_w=16, group=5, streams=3), dict(group=7, streams=1),
+                 dict(group=32, streams=2), dict(group=3, streams=4))
+GEOMETRIES_32 = (dict(tile_w=32), dict(tile_w=32, group=8, streams=2, xcd_swizzle=0), dict(tile_w=32, group=7, streams=1),
+                 dict(tile_w=32, group=32, streams=2))
+
+
+def _n1m_geometries_body(gpu, oracle, geometries):
     """Group size, stream count and tile width change how the intermediate is laid out and handed over, never
     the arithmetic: every geometry must reproduce the default result bit for bit, also when the buffer is much
     larger than L2 / Infinity Cache and execs run back to back (a stale-line hazard shows up as mismatching
@@ -205,49 +217,15 @@ def test_n1m_pipeline_geometries_are_bit_identical(gpu, oracle):
     ref, _, _ = _run(fw, dev, queue, "Forward", x, n)
     mx, _ = oracle.compare(ref[:n], oracle.dft_f64(x[:n], n, -1))
     assert mx <= REL_TOL
-    for kw in (dict(tile_w=16), dict(tile_w=32), dict(tile_w=16, xcd_swizzle=0), dict(tile_w=32, group=8, streams=2, xcd_swizzle=0),
-               dict(tile_w=16, group=5, streams=3),
-               dict(tile_w=32, group=7, streams=1), dict(tile_w=32, group=32, streams=2)):
+    for kw in geometries:
         for rep in range(2):
             y, _, _ = _run(fw, dev, queue, "Forward", x, n, **kw)
             bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
             assert bad.size == 0, (kw, rep, bad.size, bad[:8])
 
 
-@pytest.mark.parametrize("batch,depth,slots,wgs", [(4, 8, 12, 512), (5, 1, 2, 512), (17, 4, 5, 512), (40, 8, 12, 300),
-                                                    (23, 2, 7, 64), (64, 8, 9, 512), (9, 16, 20, 700)])
-def test_n1m_persistent_ring_pipeline(gpu, oracle, batch, depth, slots, wgs):
-    """path 5: the two passes as ONE persistent launch (ticket queue, in-launch hand-offs through a small ring).
-    Same arithmetic as the per-group launches: bit-identical results, and no bounded spin may have timed out."""
-    fw, dev, queue = gpu
-    n = 1 << 20
-    x = oracle.gen_input(n, batch, first_transform=batch)
-    ref, _, _ = _run(fw, dev, queue, "Forward", x, n, path=1, tile_w=16)
-    _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
-    for rep in range(2):
-        y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=5, depth=depth, ring_slots=slots, wgs=wgs)
-        assert which == 0 and plan.get("path") == 5 and plan.get("launches_per_exec") == 1
-        assert plan.get("device_error") == 0
-        bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
-        assert bad.size == 0, (batch, depth, slots, wgs, rep, bad.size, bad[:8])
-    z, _, plan = _run(fw, dev, queue, "Inverse", ref, n, path=5, depth=depth, ring_slots=slots, wgs=wgs)
-    assert plan.get("device_error") == 0
-    _check(oracle, z, x.astype(np.complex128), n)
-
-
-def test_n1m_persistent_ring_large_batch_bit_identical(gpu, oracle):
-    """768 MiB batch (far beyond L2 and Infinity Cache), ring slots reused 8 times, back-to-back execs: a stale cache
-    line anywhere in the in-launch hand-off shows up as a mismatching 128-byte line."""
-    fw, dev, queue = gpu
-    n, batch = 1 << 20, 96
-    x = oracle.gen_input(n, batch, first_transform=7)
-    ref, _, _ = _run(fw, dev, queue, "Forward", x, n, path=1)
-    for kw in (dict(), dict(depth=4, ring_slots=6), dict(depth=8, ring_slots=12, wgs=256), dict(depth=2, ring_slots=3)):
-        for rep in range(2):
-            y, _, plan = _run(fw, dev, queue, "Forward", x, n, path=5, **kw)
-            assert plan.get("device_error") == 0
-            bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
-            assert bad.size == 0, (kw, rep, bad.size, bad[:8])
+def test_n1m_pipeline_geometries_are_bit_identical(gpu, oracle):
+    _n1m_geometries_body(gpu, oracle, GEOMETRIES_16)
 
 
 def test_n1m_matches_literal_recurrence(gpu, oracle):
@@ -301,30 +279,6 @@ def test_tiled_groups_chains_ragged(gpu, oracle, lg, batch):
     # a different geometry computes the same bits
     y2, _, _ = _run(fw, dev, queue, "Forward", x, n, group=3, streams=1)
     assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
-
-
-@pytest.mark.parametrize("lg,batch,max_teams", [(16, 1, None), (16, 7, None), (16, 100, None), (16, 33, 2), (17, 5, None),
-                                                (17, 40, None), (17, 9, 1), (18, 3, None), (18, 21, None)])
-def test_team_pipeline_l2_resident(gpu, oracle, lg, batch, max_teams):
-    """path 8: both passes in ONE persistent launch, workgroups teamed up per XCD, the intermediate handed over through
-    that XCD's L2 with plain stores, sc1 loads and flag barriers.  Same tile arithmetic as the per-pass launches with the
-    same factorisation: results must be bit-identical (a stale line anywhere shows up as mismatching 128-byte lines), and
-    no bounded spin may have timed out.  Runs twice back to back on the same slabs."""
-    fw, dev, queue = gpu
-    n = 1 << lg
-    x = oracle.gen_input(n, batch, first_transform=lg)
-    f0 = lg // 2
-    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8), rows32=0, colsw=0)  # same tile arithmetic
-    _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
-    for rep in range(2):
-        y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=8, max_teams=max_teams)
-        assert plan.get("path") == 8 and plan.get("launches_per_exec") == 1 and which == which_ref == lg % 2
-        assert plan.get("device_error") == 0
-        bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
-        assert bad.size == 0, (lg, batch, rep, bad.size, bad[:8])
-    z, _, plan = _run(fw, dev, queue, "Inverse", ref, n, path=8, max_teams=max_teams)
-    assert plan.get("device_error") == 0
-    _check(oracle, z, x.astype(np.complex128), n)
 
 
 def test_tiled_default_group_with_many_groups(gpu, oracle):
@@ -684,6 +638,69 @@ def test_rejects_bad_arguments(gpu):
     enc.synchronize()
     with pytest.raises(fw.FwaError):
         fw.Forward(dev, queue, empty, 1 << 31)       # above 2^30
+
+
+def test_product_library_rejects_laboratory_settings(gpu):
+    """The product library ships one kernel per (size class, pass, direction): the laboratory paths and variants answer
+    FWA_ERR_UNSUPPORTED (6) and leave the plan as it was."""
+    fw, dev, queue = gpu
+    assert not dev.lab
+    buf = dev.create_buffer(8 << 20 << 3)      # 2^20 x 8
+    p = fw.Forward(dev, queue, buf, 1 << 20)
+    for key, val in (("path", 5), ("tile_w", 32), ("depth", 4), ("ring_slots", 6), ("wgs", 512), ("max_teams", 2)):
+        with pytest.raises(fw.FwaError) as e:
+            p.set(key, val)
+        assert e.value.status == 6, (key, e.value.status)
+    assert p.get("path") == 1 and p.get("tile_w") == 16
+    p.set("tile_w", 16)
+    small = fw.Forward(dev, queue, dev.wrap_buffer(buf.device_ptr, 8 * 4096), 64)
+    for val in (0, 2, 3):
+        with pytest.raises(fw.FwaError) as e:
+            small.set("small_reg", val)
+        assert e.value.status == 6
+    small.set("small_reg", 1)
+    mid = fw.Forward(dev, queue, dev.wrap_buffer(buf.device_ptr, 8 << 16 << 5), 1 << 16)
+    with pytest.raises(fw.FwaError) as e:
+        mid.set("path", 8)
+    assert e.value.status == 6 and mid.get("path") == 7
+
+
+def test_failed_retune_leaves_the_plan_as_it_was(gpu, oracle):
+    """a re-factorisation that cannot get its ring (device memory exhausted) must leave path, factors,
+    TABLES and results exactly as they were -- the tables of the new factorisation are handed to the plan only after its
+    pipeline has been built (before, the plan kept the old factors with the new tables)."""
+    fw, dev, queue = gpu
+    n, batch = 1 << 18, 53   # one group of 53 transforms: a 106-MiB ring, a size no earlier test has left in the ring pool
+    x = oracle.gen_input(n, batch, first_transform=3)
+    src = dev.create_buffer(x.nbytes)
+    plan = fw.Forward(dev, queue, src, n)
+    f0, path0, shared0 = plan.get("factors"), plan.get("path"), plan.get("tables_shared")
+    assert path0 == 7 and f0 == 8 | (10 << 8)
+    hog = []
+    try:
+        # exhaust the device memory down to fragments below 64 MiB (hipMemGetInfo is too coarse to stop at a byte count):
+        # the 106-MiB ring of the re-factorised plan cannot be allocated, its few KiB of tables can
+        for chunk in (64 << 30, 8 << 30, 1 << 30, 128 << 20, 64 << 20):
+            while True:
+                try:
+                    hog.append(dev.create_buffer(chunk))
+                except fw.FwaError as oom:
+                    assert oom.status == 2
+                    break
+        with pytest.raises(fw.FwaError) as e:
+            plan.set("factors", 9 | (9 << 8))
+        assert e.value.status == 2, e.value.status      # FWA_ERR_OUT_OF_MEMORY
+    finally:
+        for h in hog:
+            h.destroy()
+    assert (plan.get("factors"), plan.get("path"), plan.get("tables_shared")) == (f0, path0, shared0)
+    queue.write_buffer(src, 0, x)
+    enc = dev.create_command_encoder()
+    y = plan.proc(enc).map_read(stream=enc)
+    r = oracle.dft_f64(x, n, -1)
+    for t in (0, 1, 31, 52):
+        mx, l2 = oracle.compare(y[t * n:(t + 1) * n], r[t * n:(t + 1) * n])
+        assert mx <= REL_TOL and l2 <= REL_TOL, (t, mx, l2)
 
 
 def test_cpp_mirror_replays_reference_example(gpu, tmp_path):

@@ -17,8 +17,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--execs", type=int, default=3)
     ap.add_argument("--set", default="")
+    ap.add_argument("--lab", action="store_true", help="load the laboratory build (paths 5 / 8, tile_w = 32, small_reg != 1)")
     args = ap.parse_args()
-    dev, queue = fw.prepare_gpu(0)
+    dev, queue = fw.prepare_gpu(0, lab=args.lab)
     n = 1 << args.lg
     buf = dev.create_buffer(n * args.batch * 8)
     enc = dev.create_command_encoder()

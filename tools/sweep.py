@@ -37,8 +37,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--set", action="append", default=[], help="one plan setting (repeatable); '' = defaults")
     ap.add_argument("--copy", action="store_true", help="float4 copy rate vs footprint first")
+    ap.add_argument("--lab", action="store_true", help="load the laboratory build (paths 5 / 8, tile_w = 32, small_reg != 1)")
     args = ap.parse_args()
-    dev, queue = fw.prepare_gpu(0)
+    dev, queue = fw.prepare_gpu(0, lab=args.lab)
     n = 1 << args.lg
     nbytes = n * args.batch * 8
     buf = dev.create_buffer(nbytes)
