@@ -190,11 +190,18 @@ def main():
         value = samples_per_step / (wall_max / args.steps) / 1e9
         ev_ms = sum(step_ms_events) / len(step_ms_events)
         achieved = ALGO_BYTES_PER_SAMPLE * n * batch / (ev_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        # Figures that cannot be measured inside the timed run (PMC counters need their own rocprofv3 passes; the
+        # linear-stream floors are probe programs): read from profiles/bench_reference.json, each with its source.
+        traffic = traffic_source = floors = isolated = None
+        tpath = os.path.join(ROOT, "profiles", "bench_reference.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{n}x{batch}")
+                ref = json.load(open(tpath))
+                traffic = ref.get("traffic_bytes_per_exec", {}).get(f"{n}x{batch}")
+                traffic_source = ref.get("traffic_source") if traffic else None
+                if n == (1 << 20):
+                    floors = ref.get("measured_floors")
+                    isolated = ref.get("isolated_kernel_us")
             except Exception:
                 traffic = None
         launches = max(1, plan.get("launches_per_exec"))
@@ -212,11 +219,15 @@ def main():
             "config": {"workload": f"1-D c2c fp32 FFT N={n} batch={batch} per GPU (BASELINE.json configs[2]"
                                    f"{'; configs[3] shape' if world > 1 else ''})",
                        "fft_len": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective",
+                       "dist_backend": (dist.get_backend() if use_dist else None),
+                       "dist_world_size": (dist.get_world_size() if use_dist else None),
+                       "chain_streams_checked": dev.stats().get("chain_checks"), "chain_streams_rejected": dev.stats().get("chain_rejects"),
                        "plan_path": plan.get("path"), "group": group, "streams": chains,
                        "tile_w": plan.get("tile_w"), "launches_per_step": launches,
                        "scratch_bytes": plan.get("scratch_bytes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "measured_floors": floors, "isolated_kernel_us": isolated,
                          "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group "
                                    "of transforms, alternating over the chains)",
                          "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -79,6 +80,7 @@ struct fwa_ctx {
     // Internal chain streams of the pipelined paths: created once per context, shared by every plan, and checked at
     // creation to run kernels side by side (chain_streams() below).
     std::vector<hipStream_t> chains;
+    std::vector<hipStream_t> user_streams;  // alive streams made by fwa_stream_create, oldest first
     int64_t n_chain_checks = 0, n_chain_rejects = 0, chain_pair_us = 0, chain_single_us = 0;
 };
 struct fwa_stream {
@@ -346,17 +348,17 @@ void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
     }
 }
 
-// The chain streams.  Two HIP streams do not always run their kernels side by side on this stack: which hardware queue
-// a new stream lands on depends on what the process created and destroyed before, and a pair that shares one runs the two
-// chains of a pipelined plan strictly one after the other -- every exec of such a plan took the single-chain time
-// (+15 %: profiles/round3/probe_plan_instance_modes.txt).  So the streams are created ONCE per context, and each new one
-// is accepted only if a memory-free spin kernel on it overlaps the same kernel on all chains accepted before it
-// (pair time < 1.5 x single); a rejected stream stays alive until the search ends so that the runtime cannot hand the
-// same queue back.  Best effort: after 6 rejections the last candidate is kept (a context with more chains than the
-// runtime has hardware queues cannot overlap them all).
-int32_t chain_streams(fwa_ctx *ctx, size_t n)
+// Streams that overlap.  Two HIP streams do not always run side by side on this stack: which hardware queue a new
+// stream lands on depends on what the process created and destroyed before, and a pair that shares one runs strictly one
+// after the other -- a pipelined plan whose two chains shared a queue took the single-chain time on every exec (+15 %:
+// profiles/round3/probe_plan_instance_modes.txt), a host pipeline whose transfer streams shared one moved 21 GB/s each way
+// instead of 44.  So a stream created by this library is accepted only if a memory-free spin kernel on it overlaps the same
+// kernel on its `peers` (time on all of them at once < single + half a spin); a rejected candidate stays alive until the
+// search ends so that the runtime cannot hand the same queue back.  Best effort: after 6 rejections the last candidate is
+// kept (a process with more streams than the runtime has hardware queues cannot overlap them all).
+int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, hipStream_t *out)
 {
-    if (ctx->chains.size() >= n) return FWA_OK;
+    *out = nullptr;
     constexpr uint32_t TICKS = 4000, BLOCKS = 256;  // 40 us, one wave per CU
     hipEvent_t e0 = nullptr, e1 = nullptr, fork = nullptr;
     std::vector<hipEvent_t> done;
@@ -388,21 +390,22 @@ int32_t chain_streams(fwa_ctx *ctx, size_t n)
         }
         *us = best;
     };
-    while (ctx->chains.size() < n && e == hipSuccess) {
+    while (!*out && e == hipSuccess) {
         hipStream_t cand = nullptr;
         e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
         if (e != hipSuccess) break;
-        std::vector<hipStream_t> set = ctx->chains;
+        if (peers.empty()) { *out = cand; break; }
+        std::vector<hipStream_t> set = peers;
         set.push_back(cand);
         float single = 0, all = 0;
         timed({cand}, &single);
-        if (set.size() > 1) timed(set, &all);
+        timed(set, &all);
         ++ctx->n_chain_checks;
-        const bool overlaps = set.size() == 1 || all < single + 0.5f * (TICKS * 0.01f);
+        const bool overlaps = all < single + 0.5f * (TICKS * 0.01f);
         if (e == hipSuccess && (overlaps || rejected.size() >= 6)) {
-            ctx->chains.push_back(cand);
+            *out = cand;
             ctx->chain_single_us = (int64_t)single;
-            if (set.size() > 1) ctx->chain_pair_us = (int64_t)all;
+            ctx->chain_pair_us = (int64_t)all;
         } else {
             rejected.push_back(cand);
             ++ctx->n_chain_rejects;
@@ -411,7 +414,20 @@ int32_t chain_streams(fwa_ctx *ctx, size_t n)
     for (auto s : rejected) (void)hipStreamDestroy(s);
     for (auto d : done) (void)hipEventDestroy(d);
     for (auto ev : {e0, e1, fork}) if (ev) (void)hipEventDestroy(ev);
-    if (e != hipSuccess) return fail_hip(ctx, e, "chain stream setup");
+    if (e != hipSuccess) return fail_hip(ctx, e, "stream setup");
+    return FWA_OK;
+}
+
+// The chain streams of the pipelined paths: created once per context, shared by every plan, each checked against the
+// chains accepted before it.
+int32_t chain_streams(fwa_ctx *ctx, size_t n)
+{
+    while (ctx->chains.size() < n) {
+        hipStream_t s = nullptr;
+        int32_t st = overlapping_stream(ctx, ctx->chains, &s);
+        if (st) return st;
+        ctx->chains.push_back(s);
+    }
     return FWA_OK;
 }
 
@@ -799,11 +815,17 @@ int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
     USE_DEVICE(ctx);
+    // checked to overlap the (up to two) streams this context created most recently: a caller that makes a transfer
+    // stream and a compute stream back to back gets two that really run side by side (overlapping_stream above)
     hipStream_t s;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    std::vector<hipStream_t> peers(ctx->user_streams.end() - (std::ptrdiff_t)std::min<size_t>(2, ctx->user_streams.size()),
+                                   ctx->user_streams.end());
+    int32_t rc = overlapping_stream(ctx, peers, &s);
+    if (rc) return rc;
     fwa_stream *st = new (std::nothrow) fwa_stream;
     if (!st) { (void)hipStreamDestroy(s); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     st->ctx = ctx; st->s = s; st->owned = true;
+    ctx->user_streams.push_back(s);
     *out = st;
     return FWA_OK;
 }
@@ -829,7 +851,13 @@ int32_t fwa_stream_synchronize(fwa_stream *stream)
 int32_t fwa_stream_destroy(fwa_stream *stream)
 {
     if (!stream) return FWA_OK;
-    if (stream->owned) { (void)hipSetDevice(stream->ctx->device); (void)hipStreamDestroy(stream->s); }
+    if (stream->owned) {
+        (void)hipSetDevice(stream->ctx->device);
+        auto &us = stream->ctx->user_streams;
+        for (size_t i = 0; i < us.size(); ++i)
+            if (us[i] == stream->s) { us.erase(us.begin() + (std::ptrdiff_t)i); break; }
+        (void)hipStreamDestroy(stream->s);
+    }
     delete stream;
     return FWA_OK;
 }

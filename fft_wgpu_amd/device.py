@@ -194,7 +194,8 @@ class Device:
         """Plan-cache counters of this context (fwa_ctx_get_i64)."""
         out = {}
         for k in ("table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "last_plan_create_us", "pooled_ring_bytes",
-                  "mem_free_bytes", "mem_total_bytes"):
+                  "mem_free_bytes", "mem_total_bytes", "chain_streams", "chain_checks", "chain_rejects", "chain_single_us",
+                  "chain_pair_us"):
             v = ctypes.c_int64()
             _ffi.check(self._L.fwa_ctx_get_i64(self._h, k.encode(), ctypes.byref(v)), self._h, "fwa_ctx_get_i64", self._L)
             out[k] = v.value

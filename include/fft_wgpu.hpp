@@ -6,6 +6,9 @@
 // fft_wgpu::Error carrying the fwa_status and fwa_last_error_string().
 #pragma once
 #include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,10 +55,48 @@ public:
     CommandEncoder(const CommandEncoder &) = delete;
     fwa_stream *raw() const { return h_; }
     void synchronize() { d_.check(fwa_stream_synchronize(h_), "fwa_stream_synchronize"); }  // submit + poll(wait)
+    const Device &device() const { return d_; }
 
 private:
     const Device &d_;
     fwa_stream *h_ = nullptr;
+};
+
+class Event {  // one recorded point of an encoder's stream (no wgpu analogue: what map_async's callback stands for)
+public:
+    explicit Event(const Device &d) : d_(d) { d.check(fwa_event_create(d.raw(), &h_), "fwa_event_create"); }
+    ~Event() { fwa_event_destroy(h_); }
+    Event(const Event &) = delete;
+    void record(CommandEncoder &e) { d_.check(fwa_event_record(h_, e.raw()), "fwa_event_record"); }
+    void synchronize() { d_.check(fwa_event_synchronize(h_), "fwa_event_synchronize"); }          // host waits
+    void make_wait(CommandEncoder &e) { d_.check(fwa_stream_wait_event(e.raw(), h_), "fwa_stream_wait_event"); }  // device-side
+    float elapsed_ms(Event &end)
+    {
+        float ms = 0;
+        d_.check(fwa_event_elapsed_ms(h_, end.h_, &ms), "fwa_event_elapsed_ms");
+        return ms;
+    }
+
+private:
+    const Device &d_;
+    fwa_event *h_ = nullptr;
+};
+
+class PinnedArray {  // page-locked host staging (the reference's MAP_READ staging buffer, examples/basic.rs:50-55)
+public:
+    PinnedArray(const Device &d, uint64_t bytes) : d_(d), bytes_(bytes)
+    {
+        d.check(fwa_host_alloc(d.raw(), bytes, &p_), "fwa_host_alloc");
+    }
+    ~PinnedArray() { fwa_host_free(d_.raw(), p_); }
+    PinnedArray(const PinnedArray &) = delete;
+    void *data() const { return p_; }
+    uint64_t size() const { return bytes_; }
+
+private:
+    const Device &d_;
+    void *p_ = nullptr;
+    uint64_t bytes_;
 };
 
 class Buffer {  // wgpu::Buffer (examples/basic.rs:50-64)
@@ -69,6 +110,14 @@ public:
     void write(const void *host, uint64_t bytes, CommandEncoder *e = nullptr)  // queue.write_buffer
     {
         d_->check(fwa_buf_upload(h_, 0, host, bytes, e ? e->raw() : nullptr), "fwa_buf_upload");
+    }
+    void read_async(void *pinned_host, uint64_t bytes, CommandEncoder &e) const  // map_async without the poll: stream-ordered
+    {
+        d_->check(fwa_buf_download_async(pinned_host, h_, 0, bytes, e.raw()), "fwa_buf_download_async");
+    }
+    void copy_to(Buffer &dst, uint64_t bytes, CommandEncoder &e) const  // encoder.copy_buffer_to_buffer (basic.rs:84-90)
+    {
+        d_->check(fwa_buf_copy(dst.raw(), 0, h_, 0, bytes, e.raw()), "fwa_buf_copy");
     }
     void read(void *host, uint64_t bytes, CommandEncoder *e = nullptr) const  // map_async + poll + get_mapped_range
     {
@@ -126,6 +175,68 @@ struct Onlyinverse : detail::Plan {  // processor.rs:566-670
 };
 struct Normalize : detail::Plan {  // processor.rs:409-505
     Normalize(const Device &device, const Queue &, Buffer &buffer1, Buffer &buffer2, uint32_t fft_len) : Plan(device, FWA_NORMALIZE, buffer1, &buffer2, fft_len) {}
+};
+
+// The reference's benchmark loop (examples/basic.rs:72-127: write_buffer -> proc -> copy_buffer_to_buffer -> map / read back,
+// every iteration) as a pipeline -- the C++ twin of fft_wgpu_amd/pipeline.py::HostPipeline: pinned staging, `slots`-fold
+// buffered device buffers, two HIP streams (A: upload + transform + device copy, B: read-back) so that the read-back of
+// iteration i overlaps the upload of i + 1 (the host link is full duplex).  One device-side dependency per iteration
+// (A -> B); slot reuse is guarded by a HOST wait on the slot's read-back event, which the caller needs anyway before it
+// touches the result (a second device-side dependency B -> A costs 2x on this stack: profiles/round2/host_pipeline_probe.jsonl).
+class HostPipeline {
+public:
+    using PlanFactory = std::function<std::unique_ptr<detail::Plan>(const Device &, const Queue &, Buffer &)>;
+    HostPipeline(const Device &device, const Queue &queue, PlanFactory make_plan, uint64_t n_samples, int slots = 2)
+        : d_(device), bytes_(n_samples * sizeof(Complex)), ex_(device), down_(device)
+    {
+        for (int s = 0; s < slots; ++s) {
+            hin_.emplace_back(new PinnedArray(device, bytes_));
+            hout_.emplace_back(new PinnedArray(device, bytes_));
+            src_.emplace_back(new Buffer(device, bytes_));
+            staging_.emplace_back(new Buffer(device, bytes_));
+            plans_.emplace_back(make_plan(device, queue, *src_.back()));
+            e_ex_.emplace_back(new Event(device));
+            e_down_.emplace_back(new Event(device));
+        }
+    }
+    // Enqueue one iteration; blocks only until the slot's previous read-back (`slots` iterations ago) has finished.
+    // `data` (n_samples Complex) is copied into the slot's pinned input; nullptr re-sends what the slot holds.
+    int submit(const Complex *data = nullptr)
+    {
+        const int s = (int)(it_ % src_.size());
+        if (it_ >= src_.size()) e_down_[s]->synchronize();  // hout / staging / src / hin of iteration it - slots are free
+        if (data) std::memcpy(hin_[s]->data(), data, bytes_);
+        src_[s]->write(hin_[s]->data(), bytes_, &ex_);                 // queue.write_buffer          basic.rs:73
+        Buffer &out = plans_[s]->proc(ex_);                            // proc(&mut encoder)          basic.rs:79
+        out.copy_to(*staging_[s], bytes_, ex_);                        // copy_buffer_to_buffer       basic.rs:84-90
+        e_ex_[s]->record(ex_);
+        e_ex_[s]->make_wait(down_);
+        staging_[s]->read_async(hout_[s]->data(), bytes_, down_);      // map_async + get_mapped_range basic.rs:105-122
+        e_down_[s]->record(down_);
+        ++it_;
+        return s;
+    }
+    Complex *input(int slot) { return static_cast<Complex *>(hin_[slot]->data()); }  // fill in place, then submit(nullptr)
+    int next_slot() const { return (int)(it_ % src_.size()); }
+    void wait_slot_free(int slot) { if (it_ >= src_.size()) e_down_[slot]->synchronize(); }
+    // Wait for the read-back of `slot`; the pinned result stays valid until the slot is submitted again.
+    const Complex *result(int slot)
+    {
+        e_down_[slot]->synchronize();
+        return static_cast<const Complex *>(hout_[slot]->data());
+    }
+    void drain() { ex_.synchronize(); down_.synchronize(); }
+    uint64_t bytes_per_iteration() const { return bytes_; }
+
+private:
+    const Device &d_;
+    uint64_t bytes_;
+    CommandEncoder ex_, down_;
+    std::vector<std::unique_ptr<PinnedArray>> hin_, hout_;
+    std::vector<std::unique_ptr<Buffer>> src_, staging_;
+    std::vector<std::unique_ptr<detail::Plan>> plans_;
+    std::vector<std::unique_ptr<Event>> e_ex_, e_down_;
+    uint64_t it_ = 0;
 };
 
 }  // namespace fft_wgpu

@@ -719,6 +719,29 @@ def test_cpp_mirror_replays_reference_example(gpu, tmp_path):
     assert "max error 0" in r.stdout
 
 
+def test_cpp_host_pipeline_replays_reference_benchmark_loop(gpu, tmp_path):
+    """include/fft_wgpu.hpp::HostPipeline, the C++ twin of fft_wgpu_amd.HostPipeline: the reference's benchmark loop
+    (examples/basic.rs:72-127, n = 512 x 2500, upload + proc + copy + read-back every iteration) with pinned staging, two
+    streams and host-guarded slot reuse, EVERY read-back sample checked against the analytic DFT of its impulse input."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "example_basic_pipeline"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "example_basic_pipeline.cpp"),
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe), "200", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    print(r.stdout)
+    m = re.search(r"samples checked (\d+) max abs error ([0-9.e+-]+)", r.stdout)
+    assert m and int(m.group(1)) == 200 * 512 * 2500 and float(m.group(2)) <= REF_ABS_TOL
+    rate = float(re.search(r"pipeline only: [0-9.]+ iterations/s, ([0-9.]+) GB/s each way", r.stdout).group(1))
+    # 43.5 GB/s each way standalone (profiles/round3/host_pipeline_cpp.txt; the link carries 47 with both directions busy);
+    # as a child of this pytest process, which holds a context and streams of its own on the same GPU, about half of that
+    assert rate >= 12.0, r.stdout
+
+
 def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):
     """Forward/Inverse with odd log2 n return a view of the plan's own second buffer (processor.rs:13,153-157);
     the view must keep the plan alive, as the Rust borrow does."""
@@ -948,3 +971,32 @@ def test_plan_churn_does_not_leak_device_memory(gpu, oracle):
     kept = before["mem_free_bytes"] - after["mem_free_bytes"]
     assert after["pooled_ring_bytes"] <= 1 << 30
     assert kept <= after["pooled_ring_bytes"] - before["pooled_ring_bytes"] + (256 << 20), (kept, after)
+
+
+def test_bench_distributed_leg_runs_on_rccl(gpu):
+    """the N > 1 code path of bench.py -- process group on the "nccl" backend (= RCCL on ROCm),
+    device barrier, MAX all-reduce of the step time -- run on real RCCL under the driver's eyes.  A fresh child process
+    (never a re-exec of this one: this process has initialised the GPU) with FWA_BENCH_FORCE_DIST=1 on the one GPU of the
+    box; the 8-GPU curve itself (config C4) needs a node this pool does not hand out."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FWA_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # the parent's 32-GiB test buffers are freed by now or fit beside the child's 32 GiB (288 GB of HBM)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert np.isfinite(line["value"]) and line["value"] > 50.0, line["value"]          # Gsamples/s; ~200 on an MI355X
+    assert line["config"]["dist_backend"] == "nccl" and line["config"]["dist_world_size"] == 1
+    assert 0.2 < line["roofline"]["frac"] < 1.0 and line["roofline"]["traffic_source"]
+    assert line["cpu_baseline"] is None
