@@ -9,7 +9,7 @@ fn main() {
     let count = n * 500 * 5;
     let data = vec![Complex::new(2.1327392395, 3.033729); count];
     let bytes = (count * 8) as u64;
-    let desc = wgpu::BufferDescriptor { label: None, size: bytes, usage: 0, mapped_at_creation: false };
+    let desc = wgpu::BufferDescriptor { label: None, size: bytes, usage: wgpu::BufferUsages::STORAGE | wgpu::BufferUsages::COPY_SRC | wgpu::BufferUsages::COPY_DST, mapped_at_creation: false };
     let src = device.create_buffer(&desc);
     let buffer_b = device.create_buffer(&desc);
     let staging = device.create_buffer(&desc);

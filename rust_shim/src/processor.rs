@@ -15,8 +15,8 @@ use std::ptr;
 
 fn make_plan(device: &wgpu::Device, kind: i32, fft_len: u32, a: &wgpu::Buffer, b: Option<&wgpu::Buffer>) -> *mut fwa_plan {
     let mut p: *mut fwa_plan = ptr::null_mut();
-    let b_h = b.map(|x| x.h).unwrap_or(ptr::null_mut());
-    let st = unsafe { fwa_plan_create(device.ctx, kind, fft_len, a.h, b_h, &mut p) };
+    let b_h = b.map(|x| x.h.get()).unwrap_or(ptr::null_mut());
+    let st = unsafe { fwa_plan_create(device.ctx, kind, fft_len, a.h.get(), b_h, &mut p) };
     if st != FWA_OK {
         let msg = unsafe { std::ffi::CStr::from_ptr(fwa_last_error_string(device.ctx)) }.to_string_lossy().into_owned();
         panic!("fwa_plan_create: status {st}: {msg}");
@@ -35,9 +35,10 @@ fn exec(plan: *mut fwa_plan, encoder: &mut wgpu::CommandEncoder) -> *mut fwa_buf
     res
 }
 
-/// A non-owning view of a plan-owned buffer (the reference's `buffer_b: wgpu::Buffer` field).
+/// A non-owning view of a plan-owned buffer (the reference's `buffer_b: wgpu::Buffer` field).  Its handle sits in a
+/// `Cell` (`wgpu::Buffer::h`): `proc(&self)` fills it in on first use without writing through a shared reference.
 fn borrowed(ctx: *mut fwa_ctx, h: *mut fwa_buf) -> wgpu::Buffer {
-    wgpu::Buffer { ctx, h, owned: false }
+    wgpu::Buffer::view_of(ctx, h)
 }
 
 pub struct Forward<'a> {
@@ -67,13 +68,12 @@ impl<'a> Forward<'a> {
 
     pub fn proc(&self, encoder: &mut wgpu::CommandEncoder) -> &wgpu::Buffer {
         let res = exec(self.plan, encoder);
-        if res == self.buffer_a.h {
+        if res == self.buffer_a.h.get() {
             self.buffer_a
         } else {
-            // odd log2(fft_len): the plan-owned partner.  `&self` forbids storing the handle without interior
-            // mutability; the handle is stable for the plan's lifetime, so the view is filled in on first use.
-            let slot = &self.buffer_b as *const wgpu::Buffer as *mut wgpu::Buffer;
-            unsafe { (*slot).h = res };
+            // odd log2(fft_len): the plan-owned partner.  The handle is stable for the plan's lifetime; the view's
+            // `Cell` takes it on first use (interior mutability: no write through `&self`).
+            self.buffer_b.h.set(res);
             let _ = self.device;
             &self.buffer_b
         }
@@ -104,11 +104,10 @@ impl<'a> Inverse<'a> {
 
     pub fn proc(&self, encoder: &mut wgpu::CommandEncoder) -> &wgpu::Buffer {
         let res = exec(self.plan, encoder);
-        if res == self.buffer_a.h {
+        if res == self.buffer_a.h.get() {
             self.buffer_a
         } else {
-            let slot = &self.buffer_b as *const wgpu::Buffer as *mut wgpu::Buffer;
-            unsafe { (*slot).h = res };
+            self.buffer_b.h.set(res);
             &self.buffer_b
         }
     }
@@ -146,7 +145,7 @@ impl<'a> Normalize<'a> {
     /// (processor.rs:433-439); returns b.
     pub fn proc(&self, encoder: &mut wgpu::CommandEncoder) -> &wgpu::Buffer {
         let res = exec(self.plan, encoder);
-        if res == self.buffer_a.h { self.buffer_a } else { self.buffer_b }
+        if res == self.buffer_a.h.get() { self.buffer_a } else { self.buffer_b }
     }
 }
 impl<'a> Drop for Normalize<'a> {
@@ -180,7 +179,7 @@ impl<'a> Onlyinverse<'a> {
 
     pub fn proc(&self, encoder: &mut wgpu::CommandEncoder) -> &wgpu::Buffer {
         let res = exec(self.plan, encoder);
-        if res == self.buffer_a.h { self.buffer_a } else { self.buffer_b }
+        if res == self.buffer_a.h.get() { self.buffer_a } else { self.buffer_b }
     }
 }
 impl<'a> Drop for Onlyinverse<'a> {

@@ -1,10 +1,25 @@
-//! wgpu_helper -- UNVERIFIED SOURCE (never compiled here).  The reference declares this module (`src/lib.rs:8`) and
-//! leaves it empty; here it holds the GPU layer: the `wgpu` objects the plans (`src/processor.rs`) and the examples
-//! (`src/examples/basic.rs:6-122`) use, each a thin owner of one C-ABI handle of `include/fft_wgpu_amd.h`.
-//! Semantics follow the reference's use of wgpu: a `CommandEncoder` records work in order (one HIP stream),
-//! `Queue::submit` is the ordering point, `Device::poll(Maintain::Wait)` waits for everything submitted.
+//! wgpu_helper -- UNVERIFIED SOURCE (never compiled here: no Rust toolchain in the image or on the GPU box).  The
+//! reference declares this module (`src/lib.rs:8`) and leaves it empty; here it holds the GPU layer: every `wgpu` item the
+//! plans (`src/processor.rs`) and the three examples (`src/examples/basic.rs:6-30,50-64,68,73-122` and the same lines of
+//! `basic_inverse.rs`, `basic_inverse2.rs`) name, each a thin owner of one C-ABI handle of `include/fft_wgpu_amd.h`:
+//!
+//!   Instance::default() -> request_adapter(&RequestAdapterOptions { power_preference, .. }).await -> Option<Adapter>
+//!   adapter.features() / limits(); adapter.request_device(&DeviceDescriptor { .. }, None).await -> Result<(Device, Queue), _>
+//!   device.create_buffer(&BufferDescriptor { label, size, usage: BufferUsages::A | BufferUsages::B, mapped_at_creation })
+//!   buffer.slice(..) -> BufferSlice; slice.map_async(MapMode::Read, |_| {}); device.poll(Maintain::wait()).panic_on_timeout();
+//!   slice.get_mapped_range() -> BufferView (Deref<Target = [u8]>); buffer.unmap()
+//!   device.create_command_encoder(&CommandEncoderDescriptor { label }); encoder.copy_buffer_to_buffer(..); encoder.finish()
+//!   queue.write_buffer(&buf, offset, bytes); queue.submit(Some(command_buffer))
+//!
+//! Semantics follow the reference's use of wgpu: a `CommandEncoder` records work in order (one HIP stream), `Queue::submit`
+//! is the ordering point, `Device::poll(Maintain::Wait)` waits for everything submitted, a mapped range is a host copy of
+//! the buffer taken after that wait.  The futures are ready on first poll (there is nothing to wait for: the HIP context
+//! is created synchronously), so `#[tokio::main]` callers keep their `.await`s.
 use crate::ffi::*;
+use std::cell::{Cell, RefCell};
 use std::ffi::CStr;
+use std::future::{ready, Ready};
+use std::ops::{BitOr, Deref, RangeBounds};
 use std::os::raw::c_void;
 use std::ptr;
 
@@ -16,7 +31,84 @@ fn check(ctx: *const fwa_ctx, st: i32, what: &str) {
     }
 }
 
-/// `wgpu::Device` (+ Instance + Adapter): one context per GPU ordinal.
+// ---- Instance / Adapter (examples/basic.rs:6-30, src/lib.rs:29-62) -------------------------------------------------
+/// `wgpu::Instance`: nothing to hold -- HIP needs no loader object.
+#[derive(Default)]
+pub struct Instance;
+
+/// `wgpu::PowerPreference`
+#[derive(Clone, Copy, Default, PartialEq, Eq, Debug)]
+pub enum PowerPreference {
+    #[default]
+    None,
+    LowPower,
+    HighPerformance,
+}
+
+/// `wgpu::RequestAdapterOptions` as far as the reference fills it (`power_preference`, the rest defaulted).
+#[derive(Default)]
+pub struct RequestAdapterOptions {
+    pub power_preference: PowerPreference,
+    pub force_fallback_adapter: bool,
+    pub compatible_surface: Option<()>,
+}
+
+/// `wgpu::Features` / `wgpu::Limits`: opaque here (the reference only passes the adapter's own values back).
+#[derive(Clone, Copy, Default, Debug)]
+pub struct Features;
+#[derive(Clone, Copy, Default, Debug)]
+pub struct Limits;
+
+/// `wgpu::DeviceDescriptor`
+#[derive(Default)]
+pub struct DeviceDescriptor<'a> {
+    pub label: Option<&'a str>,
+    pub required_features: Features,
+    pub required_limits: Limits,
+}
+
+#[derive(Debug)]
+pub struct RequestDeviceError(pub String);
+
+/// `wgpu::Adapter`: a GPU ordinal that was found usable.
+pub struct Adapter {
+    ordinal: i32,
+}
+
+impl Instance {
+    /// `None` when no gfx950 device is visible (`prepare_gpu` -> `None`, `src/lib.rs:43`).
+    pub fn request_adapter(&self, _options: &RequestAdapterOptions) -> Ready<Option<Adapter>> {
+        let mut n: i32 = 0;
+        let st = unsafe { fwa_device_count(&mut n) };
+        ready(if st == FWA_OK && n > 0 { Some(Adapter { ordinal: 0 }) } else { None })
+    }
+}
+
+impl Adapter {
+    pub fn features(&self) -> Features {
+        Features
+    }
+    pub fn limits(&self) -> Limits {
+        Limits
+    }
+    /// `adapter.request_device(&desc, None).await` (`examples/basic.rs:20-30`; the second argument is wgpu 23/24's trace path)
+    pub fn request_device(
+        &self,
+        _desc: &DeviceDescriptor,
+        _trace_path: Option<&std::path::Path>,
+    ) -> Ready<Result<(Device, Queue), RequestDeviceError>> {
+        ready(match Device::open(self.ordinal) {
+            Some(d) => {
+                let q = d.queue();
+                Ok((d, q))
+            }
+            None => Err(RequestDeviceError("no usable gfx950 device".into())),
+        })
+    }
+}
+
+// ---- Device / Queue ------------------------------------------------------------------------------------------------
+/// `wgpu::Device`: one context per GPU ordinal.
 pub struct Device {
     pub(crate) ctx: *mut fwa_ctx,
     owner: bool,
@@ -33,19 +125,60 @@ pub enum Maintain {
     Poll,
 }
 impl Maintain {
-    /// wgpu 23/24 spelling used by the reference (`src/lib.rs:226`)
+    /// wgpu 23/24 spelling used by the reference (`src/lib.rs:226`, `examples/basic.rs:106`)
     pub fn wait() -> Self {
         Maintain::Wait
     }
 }
+/// `wgpu::MaintainResult`
+pub enum MaintainResult {
+    SubmissionQueueEmpty,
+    Ok,
+}
+impl MaintainResult {
+    /// `device.poll(..).panic_on_timeout()` (`examples/basic.rs:106`): a failed wait has already panicked in `poll`.
+    pub fn panic_on_timeout(self) {}
+}
 
-/// `wgpu::BufferDescriptor` as far as the reference fills it (`examples/basic.rs:50-64`): usage flags are accepted
-/// and ignored (every buffer is device memory usable as STORAGE | COPY_SRC | COPY_DST).
+/// `wgpu::BufferUsages`: accepted and ignored -- every buffer is device memory usable as STORAGE | COPY_SRC | COPY_DST,
+/// and any buffer can be read back through `slice(..).map_async` (a staged host copy).
+#[derive(Clone, Copy, PartialEq, Eq, Debug, Default)]
+pub struct BufferUsages(pub u32);
+impl BufferUsages {
+    pub const MAP_READ: BufferUsages = BufferUsages(1 << 0);
+    pub const MAP_WRITE: BufferUsages = BufferUsages(1 << 1);
+    pub const COPY_SRC: BufferUsages = BufferUsages(1 << 2);
+    pub const COPY_DST: BufferUsages = BufferUsages(1 << 3);
+    pub const INDEX: BufferUsages = BufferUsages(1 << 4);
+    pub const VERTEX: BufferUsages = BufferUsages(1 << 5);
+    pub const UNIFORM: BufferUsages = BufferUsages(1 << 6);
+    pub const STORAGE: BufferUsages = BufferUsages(1 << 7);
+    pub const fn empty() -> Self {
+        BufferUsages(0)
+    }
+    pub const fn contains(self, other: BufferUsages) -> bool {
+        self.0 & other.0 == other.0
+    }
+}
+impl BitOr for BufferUsages {
+    type Output = BufferUsages;
+    fn bitor(self, rhs: BufferUsages) -> BufferUsages {
+        BufferUsages(self.0 | rhs.0)
+    }
+}
+
+/// `wgpu::BufferDescriptor` (`examples/basic.rs:50-64`)
 pub struct BufferDescriptor<'a> {
     pub label: Option<&'a str>,
     pub size: u64,
-    pub usage: u32,
+    pub usage: BufferUsages,
     pub mapped_at_creation: bool,
+}
+
+/// `wgpu::CommandEncoderDescriptor` (`examples/basic.rs:76-77`)
+#[derive(Default)]
+pub struct CommandEncoderDescriptor<'a> {
+    pub label: Option<&'a str>,
 }
 
 impl Device {
@@ -65,17 +198,18 @@ impl Device {
     pub fn create_buffer(&self, desc: &BufferDescriptor) -> Buffer {
         let mut h: *mut fwa_buf = ptr::null_mut();
         check(self.ctx, unsafe { fwa_buf_alloc(self.ctx, desc.size, &mut h) }, "fwa_buf_alloc");
-        Buffer { ctx: self.ctx, h, owned: true }
+        Buffer { ctx: self.ctx, h: Cell::new(h), owned: true, map_requested: Cell::new(false), mapped: RefCell::new(None) }
     }
-    /// `create_command_encoder(&Default::default())` (`examples/basic.rs:76`)
+    /// `device.create_command_encoder(&wgpu::CommandEncoderDescriptor { label: None })` (`examples/basic.rs:76-77`)
     pub fn create_command_encoder(&self, _desc: &CommandEncoderDescriptor) -> CommandEncoder {
         let mut s: *mut fwa_stream = ptr::null_mut();
         check(self.ctx, unsafe { fwa_stream_create(self.ctx, &mut s) }, "fwa_stream_create");
         CommandEncoder { ctx: self.ctx, s }
     }
     /// `device.poll(wgpu::Maintain::wait())` (`examples/basic.rs:106`): all submitted work has completed on return.
-    pub fn poll(&self, _maintain: Maintain) {
+    pub fn poll(&self, _maintain: Maintain) -> MaintainResult {
         check(self.ctx, unsafe { fwa_ctx_synchronize(self.ctx) }, "fwa_ctx_synchronize");
+        MaintainResult::SubmissionQueueEmpty
     }
 }
 impl Drop for Device {
@@ -86,32 +220,98 @@ impl Drop for Device {
     }
 }
 
-#[derive(Default)]
-pub struct CommandEncoderDescriptor;
-
-/// `wgpu::Buffer`
+// ---- Buffer / BufferSlice / BufferView -----------------------------------------------------------------------------
+/// `wgpu::Buffer`.  The handle sits in a `Cell`: the plans resolve their plan-owned second buffer on the first `proc(&self)`
+/// (`processor.rs`), which must not write through a shared reference without interior mutability.
 pub struct Buffer {
     pub(crate) ctx: *mut fwa_ctx,
-    pub(crate) h: *mut fwa_buf,
+    pub(crate) h: Cell<*mut fwa_buf>,
     pub(crate) owned: bool,
+    map_requested: Cell<bool>,
+    mapped: RefCell<Option<Vec<u8>>>,
 }
+/// `wgpu::MapMode`
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub enum MapMode {
+    Read,
+    Write,
+}
+#[derive(Debug)]
+pub struct BufferAsyncError;
+
+/// `wgpu::BufferSlice`: the reference only ever takes the whole buffer (`staging_buffer.slice(..)`, `examples/basic.rs:68`).
+pub struct BufferSlice<'a> {
+    buffer: &'a Buffer,
+    offset: u64,
+    size: u64,
+}
+/// `wgpu::BufferView`: a host copy of the mapped range (`bytemuck::cast_slice(&data1)`, `examples/basic.rs:107-113`).
+pub struct BufferView {
+    data: Vec<u8>,
+}
+impl Deref for BufferView {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] {
+        &self.data
+    }
+}
+impl AsRef<[u8]> for BufferView {
+    fn as_ref(&self) -> &[u8] {
+        &self.data
+    }
+}
+
 impl Buffer {
+    pub(crate) fn view_of(ctx: *mut fwa_ctx, h: *mut fwa_buf) -> Buffer {
+        Buffer { ctx, h: Cell::new(h), owned: false, map_requested: Cell::new(false), mapped: RefCell::new(None) }
+    }
     /// bytes (`src.size()`, `processor.rs:30`)
     pub fn size(&self) -> u64 {
-        unsafe { fwa_buf_size(self.h) }
+        unsafe { fwa_buf_size(self.h.get()) }
     }
-    /// Blocking read-back: `slice(..).map_async` + `device.poll(wait)` + `get_mapped_range` + `unmap`
-    /// (`examples/basic.rs:105-122`) in one call.
+    /// `buffer.slice(..)` (`examples/basic.rs:68`)
+    pub fn slice<R: RangeBounds<u64>>(&self, range: R) -> BufferSlice<'_> {
+        use std::ops::Bound::*;
+        let start = match range.start_bound() { Included(&a) => a, Excluded(&a) => a + 1, Unbounded => 0 };
+        let end = match range.end_bound() { Included(&b) => b + 1, Excluded(&b) => b, Unbounded => self.size() };
+        BufferSlice { buffer: self, offset: start, size: end - start }
+    }
+    /// `staging_buffer.unmap()` (`examples/basic.rs:122`): drops the host copy.
+    pub fn unmap(&self) {
+        self.map_requested.set(false);
+        *self.mapped.borrow_mut() = None;
+    }
+    /// Blocking read-back in one call: `slice(..).map_async` + `device.poll(wait)` + `get_mapped_range` + `unmap`.
     pub fn read_to(&self, host: &mut [u8]) {
         check(self.ctx, unsafe { fwa_ctx_synchronize(self.ctx) }, "fwa_ctx_synchronize");
-        let st = unsafe { fwa_buf_download(host.as_mut_ptr() as *mut c_void, self.h, 0, host.len() as u64, ptr::null_mut()) };
+        let st = unsafe { fwa_buf_download(host.as_mut_ptr() as *mut c_void, self.h.get(), 0, host.len() as u64, ptr::null_mut()) };
         check(self.ctx, st, "fwa_buf_download");
+    }
+}
+impl<'a> BufferSlice<'a> {
+    /// `buffer_slice.map_async(wgpu::MapMode::Read, move |_| {})` (`examples/basic.rs:105`): the request is noted and the
+    /// callback runs at once with `Ok(())` -- the bytes are fetched by `get_mapped_range` after the caller's `poll(wait)`.
+    pub fn map_async(&self, _mode: MapMode, callback: impl FnOnce(Result<(), BufferAsyncError>) + Send + 'static) {
+        self.buffer.map_requested.set(true);
+        callback(Ok(()));
+    }
+    /// `buffer_slice.get_mapped_range()` (`examples/basic.rs:107`): waits for all submitted work (what the caller's
+    /// `poll(wait)` already did) and copies the range to the host.
+    pub fn get_mapped_range(&self) -> BufferView {
+        assert!(self.buffer.map_requested.get(), "get_mapped_range() without map_async()");
+        let mut data = vec![0u8; self.size as usize];
+        check(self.buffer.ctx, unsafe { fwa_ctx_synchronize(self.buffer.ctx) }, "fwa_ctx_synchronize");
+        let st = unsafe {
+            fwa_buf_download(data.as_mut_ptr() as *mut c_void, self.buffer.h.get(), self.offset, self.size, ptr::null_mut())
+        };
+        check(self.buffer.ctx, st, "fwa_buf_download");
+        BufferView { data }
     }
 }
 impl Drop for Buffer {
     fn drop(&mut self) {
         if self.owned {
-            unsafe { fwa_buf_free(self.h) };
+            unsafe { fwa_buf_free(self.h.get()) };
         }
     }
 }
@@ -119,7 +319,7 @@ impl Drop for Buffer {
 impl Queue {
     /// `queue.write_buffer(&src, 0, bytemuck::cast_slice(&data))` (`examples/basic.rs:73`)
     pub fn write_buffer(&self, buffer: &Buffer, offset: u64, data: &[u8]) {
-        let st = unsafe { fwa_buf_upload(buffer.h, offset, data.as_ptr() as *const c_void, data.len() as u64, ptr::null_mut()) };
+        let st = unsafe { fwa_buf_upload(buffer.h.get(), offset, data.as_ptr() as *const c_void, data.len() as u64, ptr::null_mut()) };
         check(self.ctx, st, "fwa_buf_upload");
         // the null stream is synchronous with respect to later encoder streams only after this wait
         check(self.ctx, unsafe { fwa_ctx_synchronize(self.ctx) }, "fwa_ctx_synchronize");
@@ -146,7 +346,7 @@ pub struct CommandBuffer {
 impl CommandEncoder {
     /// `encoder.copy_buffer_to_buffer(output, 0, &staging, 0, size)` (`examples/basic.rs:84-90`)
     pub fn copy_buffer_to_buffer(&mut self, src: &Buffer, src_offset: u64, dst: &Buffer, dst_offset: u64, size: u64) {
-        let st = unsafe { fwa_buf_copy(dst.h, dst_offset, src.h, src_offset, size, self.s) };
+        let st = unsafe { fwa_buf_copy(dst.h.get(), dst_offset, src.h.get(), src_offset, size, self.s) };
         check(self.ctx, st, "fwa_buf_copy");
     }
     pub fn finish(self) -> CommandBuffer {
