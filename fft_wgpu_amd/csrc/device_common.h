@@ -8,6 +8,9 @@
 #ifndef FWA_STAMP
 #define FWA_STAMP(slot)
 #endif
+#ifndef FWA_STAMP_B  // the last-pass kernels, so that a probe can tell two concurrently running kernels apart
+#define FWA_STAMP_B(slot) FWA_STAMP(slot)
+#endif
 #ifndef FWA_ENTRY_HOOK
 #define FWA_ENTRY_HOOK()
 #endif

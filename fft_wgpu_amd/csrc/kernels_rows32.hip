@@ -22,8 +22,12 @@ static void rows32_geometry(uint32_t lg_l, uint32_t *rw, uint32_t *threads, int 
 {
     *rw = (uint32_t)rows32_rows((int)lg_l);
     *threads = *rw << (lg_l - 5);
-    const int n = 1 << lg_l, pn = n + n / 32, pns = pn + ((17 - pn % 32) + 32) % 32;
-    *lds = (int)*rw * pns * 4;
+    switch (lg_l) {
+        case 9: *lds = Rows32<9, rows32_rows(9)>::LDS_BYTES; break;
+        case 10: *lds = Rows32<10, rows32_rows(10)>::LDS_BYTES; break;
+        case 11: *lds = Rows32<11, rows32_rows(11)>::LDS_BYTES; break;
+        default: *lds = Rows32<12, rows32_rows(12)>::LDS_BYTES; break;
+    }
 }
 
 // > 64 KiB of dynamic LDS needs the attribute once per device (plan setup)

@@ -13,7 +13,7 @@ namespace fwa {
 // costs nothing extra: the last register stage is free to pick its operands from ANY row's exchange buffer, so the
 // thread that was (row xf = tid / T, butterfly t = tid % T) while loading becomes (row r = tid % 16, butterfly
 // kk = tid / 16) for the last stage -- its outputs K2 then sit beside those of the 15 other rows of the same K2 and a
-// store instruction writes 128-byte segments.  Row buffers are skewed to 17 mod 32 floats so that the 16 rows read
+// store instruction writes 128-byte segments.  Row buffers are skewed (Rows32::SKEW floats mod 32) so that the rows read
 // by one instruction fall on different banks.  RW*T threads and RW*PNS*4 bytes of LDS: 256 / 34 KiB at 512-point rows,
 // 512 / 69 KiB at 1024, 512 / 68 KiB at 2048 and 1024 / 136 KiB at 4096 (RW = 8 there, see rows32_rows).
 // (k_tile covers these lengths with 16 points per thread and two full-complex exchanges: 512-point rows were the slow
@@ -23,7 +23,12 @@ template <int LGN, int RW = 16>
 struct Rows32 {
     static constexpr int N = 1 << LGN, T = N / 32, WG = RW * T;
     static constexpr int PN = N + N / 32;
-    static constexpr int PNS = PN + ((17 - PN % 32) + 32) % 32;  // padded floats per row, = 17 mod 32
+    // Padded floats per row.  In the transposed role a 32-lane group of a ds_read_b32 / ds_write_b32 holds RW adjacent
+    // rows x 32/RW adjacent positions: with a row skew of 32/RW floats (mod 32) the RW x 32/RW addresses fall on 32
+    // different banks (RW = 8: 4, RW = 16: 2); from 32 rows on, any odd skew does.  (Round 2 used 17 for every RW: one
+    // 2-way conflict per access at 16 rows, 20 % conflict cycles at 8 rows: profiles/round3/pmc_counters_sizes_2p21_2p24.txt.)
+    static constexpr int SKEW = RW >= 32 ? 17 : 32 / RW;
+    static constexpr int PNS = PN + ((SKEW - PN % 32) + 32) % 32;
     static constexpr int LDS_BYTES = RW * PNS * 4;
 };
 
@@ -85,9 +90,9 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
 
     v2f x[32];
     FWA_ENTRY_HOOK();
-    FWA_STAMP(0);
+    FWA_STAMP_B(0);
     static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_DEFAULT>(rin, voff, m * mstep); });
-    FWA_STAMP(1);
+    FWA_STAMP_B(1);
     fft_reg<32, DIR>(x);
     twiddle_outputs<32, N, DIR>(x, tw, t);
     // transposed store role: output K2 of row r goes to element (16*tile + r) + n1*K2
@@ -141,7 +146,7 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
             });
         });
     }
-    FWA_STAMP(3);
+    FWA_STAMP_B(3);
 }
 
 // kernel entry points by row length; lg_l = 11, 12 live in kernels_rows32b.hip

@@ -16,11 +16,11 @@ namespace fwa {
 // 128 KiB; measured 0.37 / 0.40 -> 0.63 / 0.66 of the roofline).  Same Stockham recurrence per stage, radix R: idx = s*J + j, inputs idx + m*n/R, output q at
 // s*R*J + j + q*J times W_n^{s*J*q}.  Positions are padded by one float per 32 (conflict-free b32 accesses).
 // ---------------------------------------------------------------------------
+// The body for workgroup index `blk` (k_small32: blk = blockIdx.x; tools/small32_persist_probe.hip walks it through a
+// persistent loop, measured no faster: profiles/round3/probe_small32_persistent_negative.txt).
 template <int LGN, int DIR>
-__global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_small32(const v2f *__restrict__ src,
-                                                                                    v2f *__restrict__ dst,
-                                                                                    const v2f *__restrict__ tw,
-                                                                                    uint64_t batch, float scale)
+__device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *__restrict__ dst, const v2f *__restrict__ tw,
+                                             uint64_t batch, float scale, uint64_t blk, uint32_t tid)
 {
     static_assert(LGN >= 9 && LGN <= 15, "k_small32 covers n = 512 .. 32768");
     constexpr int N = 1 << LGN;
@@ -34,12 +34,12 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
     constexpr int J2 = 32 * R1;
     constexpr int PN = N + N / 32;                              // padded floats per transform
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t xf = threadIdx.x / T, t = threadIdx.x % T;
+    const uint32_t xf = tid / T, t = tid % T;
     float *lf = reinterpret_cast<float *>(smem) + xf * PN;
     // buffer (SRD) addressing: one per-lane offset, the per-access part is a scalar (no address VGPR per access); the
     // descriptor ends with the last valid transform of the batch, so surplus lanes of a ragged last workgroup read
     // zeros and their stores are dropped
-    const uint64_t first = (uint64_t)blockIdx.x * XPW;
+    const uint64_t first = blk * XPW;
     const uint64_t left = batch - first;
     const uint32_t valid_bytes = (uint32_t)(left < (uint64_t)XPW ? left : (uint64_t)XPW) * (N * 8u);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + first * N), 0, valid_bytes, 0x00020000);
@@ -114,6 +114,15 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
             });
         });
     }
+}
+
+template <int LGN, int DIR>
+__global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_small32(const v2f *__restrict__ src,
+                                                                                    v2f *__restrict__ dst,
+                                                                                    const v2f *__restrict__ tw,
+                                                                                    uint64_t batch, float scale)
+{
+    small32_body<LGN, DIR>(src, dst, tw, batch, scale, blockIdx.x, threadIdx.x);
 }
 
 static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }  // lg_n >= 6

@@ -103,6 +103,7 @@ __device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, 
 
     fft_reg<32, DIR>(x);  // x[brev(k2)] = FFT1024 output K1 = q + 32*k2
 
+    FWA_STAMP(2);
     // four-step twiddle W_N^{n2*K1} = A[q][c] * B[k2][c]
     const v2f A = two[q * W + c];
     const uint32_t voff_o = (q * W + c) * 8;
@@ -133,12 +134,12 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(in), rout = make_rsrc(out);
     v2f x[32];
     FWA_ENTRY_HOOK();
-    FWA_STAMP(0);
+    FWA_STAMP_B(0);
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         x[j] = buf_load<AUX_IN>(rin, voff_in, soff_in + j * 262144);
     });
-    FWA_STAMP(1);
+    FWA_STAMP_B(1);
     after_load();
 
     stage1_fft_twiddle<DIR>(x, twi, np);
@@ -170,13 +171,14 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
 
     fft_reg<32, DIR>(x);  // x[brev(k2)] = row FFT output K2 = k1p + 32*k2
 
+    FWA_STAMP_B(2);
     const uint32_t voff_out = (k1p * 1024 + r2) * 8;
     const uint32_t soff_out = tile * (W * 8);
     static_for<0, 32>([&](auto k_) {
         constexpr int k2 = decltype(k_)::value;
         buf_store<AUX_NT>(x[brev<32>(k2)] * scale, rout, voff_out, soff_out + k2 * 262144);
     });
-    FWA_STAMP(3);
+    FWA_STAMP_B(3);
 }
 
 // XCD-aware block -> tile mapping (cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, so
