@@ -126,6 +126,8 @@ struct fwa_plan {
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
     int64_t colsw = 0;             // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) as pass A, 0 = k_tile
     int64_t tile_ring = 1;         // k_colsw + k_rows32: 1 = tile-contiguous ring slab, 0 = matrix layout
+    int64_t ring_rotate = 1;       // laboratory: the ring is this many times larger and the groups rotate through it (same
+                                   // launches, larger cache footprint: prices what the Infinity Cache gives the ring)
     int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
@@ -505,7 +507,7 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
     if (n_streams < 1) n_streams = 1;
     if ((uint64_t)n_streams > n_groups && n_groups) n_streams = (int64_t)n_groups;
     Pipeline pl;
-    pl.ring_bytes = p->batch ? (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->n * sizeof(v2f) : 0;
+    pl.ring_bytes = p->batch ? (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->n * sizeof(v2f) * (uint64_t)p->ring_rotate : 0;
     auto bail = [&](int32_t st) { destroy_pipeline_objects(ctx, pl, false); return st; };
     if (pl.ring_bytes) {
         if (void *pooled = pool_take(ctx, pl.ring_bytes)) {
@@ -1156,7 +1158,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
             const uint32_t swz = plan->xcd_swizzle < 0 ? 1u : (uint32_t)plan->xcd_swizzle;
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
-                v2f *slab = plan->ring + (uint64_t)c * G * N;  // ring region of this chain: transform i -> slot i
+                // ring region of this chain: transform i -> slot i (ring_rotate > 1, laboratory: successive groups of a
+                // chain walk through ring_rotate such regions)
+                v2f *slab = plan->ring + ((g / (plan->istreams.empty() ? 1 : plan->istreams.size())) % (uint64_t)plan->ring_rotate) *
+                                             (uint64_t)plan->n_streams * G * N + (uint64_t)c * G * N;
                 hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt, swz, s);
                 if (le != hipSuccess) return le;
                 return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale, swz, s);
@@ -1285,6 +1290,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "rows32") *value = plan->rows32;
     else if (k == "colsw") *value = plan->colsw;
     else if (k == "tile_ring") *value = plan->tile_ring;
+    else if (k == "ring_rotate") *value = plan->ring_rotate;
     else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
     else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
     else if (k == "scratch_bytes")
@@ -1315,6 +1321,16 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths (2^20 two-pass, tiled)");
         if (value < 1 || value > (k == "streams" ? 16 : 4096)) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         return build_pipeline(plan, k == "group" ? value : plan->group, k == "streams" ? value : plan->n_streams);
+    }
+    if (k == "ring_rotate") {
+        if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "ring_rotate is a laboratory knob (libfft_wgpu_amd_lab.so)");
+        if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
+        if (value < 1 || value > 64) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        const int64_t old = plan->ring_rotate;
+        plan->ring_rotate = value;
+        const int32_t st = build_pipeline(plan, plan->group, plan->n_streams);
+        if (st) plan->ring_rotate = old;
+        return st;
     }
     if (k == "tile_w") {
         if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
