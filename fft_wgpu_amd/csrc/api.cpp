@@ -132,7 +132,8 @@ struct fwa_plan {
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
-    hipEvent_t ev_last = nullptr;  // recorded on the caller's stream by every exec that used the ring (fwa_plan_destroy waits for it)
+    hipStream_t last_stream = nullptr;  // the caller's stream of the last exec that used the ring: fwa_plan_destroy waits for the
+    bool ran_on_stream = false;         // work enqueued there (an event per exec would cost 4-5 us on the 1-3-launch latency shapes)
     // persistent 2^20 pipeline (PATH_RING_1M)
     uint32_t *ring_ctl = nullptr;  // ticket, error word, per-transform hand-off counters
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
@@ -531,10 +532,6 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
             }
         }
     }
-    if (!p->ev_last) {
-        hipError_t e = hipEventCreateWithFlags(&p->ev_last, hipEventDisableTiming);
-        if (e != hipSuccess) { p->ev_last = nullptr; return bail(fail_hip(ctx, e, "hipEventCreate")); }
-    }
     Pipeline old = take_pipeline(p);
     destroy_pipeline_objects(ctx, old, true);
     p->ring = pl.ring; p->ring_bytes = pl.ring_bytes; p->istreams.swap(pl.streams); p->idone.swap(pl.done);
@@ -682,7 +679,8 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
             HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
         }
     }
-    if (plan->ev_last) HIP_TRY(ctx, hipEventRecord(plan->ev_last, st));
+    plan->last_stream = st;
+    plan->ran_on_stream = true;
     return FWA_OK;
 }
 
@@ -996,14 +994,25 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
     (void)hipSetDevice(plan->ctx->device);
     // work of this plan may still be in flight on the caller's stream; the pooled ring must not be handed to the
     // next plan before it has drained (hipFree would have synchronised implicitly).  Only THIS plan's last exec is
-    // waited for -- other streams and contexts keep running (a device-wide synchronise here stalled them all and is
-    // illegal while any stream captures a graph).  An exec that was captured into a graph records nothing real: the
-    // plan must outlive the graphs that replay it.
-    if (plan->ev_last) {
-        if (plan->frozen && plan->ring) (void)hipEventSynchronize(plan->ev_last);
-        (void)hipEventDestroy(plan->ev_last);
-    } else if (plan->frozen && plan->ring) {
-        (void)hipDeviceSynchronize();  // persistent-launch paths (no per-exec event)
+    // waited for, through a marker on the stream that exec was enqueued on -- other streams and contexts keep running (a
+    // device-wide synchronise here stalled them all and is illegal while any stream captures a graph).  An exec that was
+    // captured into a graph enqueued nothing real: the plan must outlive the graphs that replay it.
+    if (plan->frozen && plan->ring) {
+        hipEvent_t ev = nullptr;
+        bool waited = false;
+        // only a stream that is known to be alive can take the marker: the null stream, or a stream of this context's own
+        // making that has not been destroyed (HIP does not validate stream handles); otherwise the device-wide wait below
+        const auto &us = plan->ctx->user_streams;
+        const bool alive = plan->last_stream == nullptr || std::find(us.begin(), us.end(), plan->last_stream) != us.end();
+        if (plan->ran_on_stream && alive && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            // everything this plan enqueued on its last caller stream precedes this marker
+            if (hipEventRecord(ev, plan->last_stream) == hipSuccess) waited = hipEventSynchronize(ev) == hipSuccess;
+            (void)hipEventDestroy(ev);
+        }
+        if (!waited) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();  // the stream is gone or not ours (fwa_stream_wrap), or a laboratory persistent path
+        }
     }
     Pipeline pl = take_pipeline(plan);
     destroy_pipeline_objects(plan->ctx, pl, true);
