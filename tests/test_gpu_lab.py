@@ -39,6 +39,21 @@ def test_n1m_tile_w32_geometries_are_bit_identical(gpu, oracle):
     _n1m_geometries_body(gpu, oracle, GEOMETRIES_32)
 
 
+def test_n1m_ring_rotate_is_bit_identical(gpu, oracle):
+    """Laboratory knob "ring_rotate" (the groups walk through a ring R times larger: same launches, larger cache footprint --
+    the measurement behind DESIGN.md 4.2 item 7): same results bit for bit, scratch grows R-fold."""
+    fw, dev, queue = gpu
+    n, batch = 1 << 20, 40
+    x = oracle.gen_input(n, batch, first_transform=9)
+    ref, _, plan0 = _run(fw, dev, queue, "Forward", x, n, group=4, streams=2)
+    mx, _ = oracle.compare(ref[:n], oracle.dft_f64(x[:n], n, -1))
+    assert mx <= REL_TOL
+    for rot in (2, 5):
+        y, _, plan = _run(fw, dev, queue, "Forward", x, n, group=4, streams=2, ring_rotate=rot)
+        assert plan.get("ring_rotate") == rot and plan.get("scratch_bytes") == rot * plan0.get("scratch_bytes")
+        assert np.array_equal(y.view(np.uint64), ref.view(np.uint64))
+
+
 @pytest.mark.parametrize("batch,depth,slots,wgs", [(4, 8, 12, 512), (5, 1, 2, 512), (17, 4, 5, 512), (40, 8, 12, 300),
                                                     (23, 2, 7, 64), (64, 8, 9, 512), (9, 16, 20, 700)])
 def test_n1m_persistent_ring_pipeline(gpu, oracle, batch, depth, slots, wgs):
