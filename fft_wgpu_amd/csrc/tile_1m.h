@@ -3,6 +3,21 @@
 #pragma once
 #include "device_common.h"
 
+// Cache policy of the ring accesses (measured: stores sc1 = write-through, loads default); overridable at compile time
+// for the policy A/B of tools/run_r3_policies.sh only.
+#ifndef FWA_RING_ST_AUX
+#define FWA_RING_ST_AUX AUX_SC1
+#endif
+#ifndef FWA_RING_LD_AUX
+#define FWA_RING_LD_AUX AUX_DEFAULT
+#endif
+#ifndef FWA_USER_LD_AUX
+#define FWA_USER_LD_AUX AUX_NT
+#endif
+#ifndef FWA_USER_ST_AUX
+#define FWA_USER_ST_AUX AUX_NT
+#endif
+
 namespace fwa {
 
 // ---------------------------------------------------------------------------
@@ -72,7 +87,7 @@ __device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, 
     FWA_STAMP(0);
     static_for<0, 32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        x[j] = buf_load<AUX_NT>(rin, voff, soff + j * 262144);
+        x[j] = buf_load<FWA_USER_LD_AUX>(rin, voff, soff + j * 262144);
     });
     FWA_STAMP(1);
     reinterpret_cast<v4f *>(two)[tid] = reinterpret_cast<const v4f *>(tw_outer_tile)[tid];
@@ -111,7 +126,7 @@ __device__ __forceinline__ void p1_tile(const v2f *in, v2f *out, uint32_t tile, 
     static_for<0, 32>([&](auto k_) {
         constexpr int k2 = decltype(k_)::value;
         const v2f w = cmul(A, two[32 * W + k2 * W + c]);
-        buf_store<AUX_SC1>(cmul_tw<DIR>(x[brev<32>(k2)], w), rout, voff_o, soff_o + k2 * (32 * W * 8));
+        buf_store<FWA_RING_ST_AUX>(cmul_tw<DIR>(x[brev<32>(k2)], w), rout, voff_o, soff_o + k2 * (32 * W * 8));
     });
     FWA_STAMP(3);
 }
@@ -176,7 +191,7 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
     const uint32_t soff_out = tile * (W * 8);
     static_for<0, 32>([&](auto k_) {
         constexpr int k2 = decltype(k_)::value;
-        buf_store<AUX_NT>(x[brev<32>(k2)] * scale, rout, voff_out, soff_out + k2 * 262144);
+        buf_store<FWA_USER_ST_AUX>(x[brev<32>(k2)] * scale, rout, voff_out, soff_out + k2 * 262144);
     });
     FWA_STAMP_B(3);
 }
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(32 * W) void k_p2_1m(const v2f *__restrict__ ring, 
     // Infinity Cache when this launch starts)
     const uint64_t t = (xcd_swizzle & 2u) ? (gridDim.x / G::TILES - 1) - bid / G::TILES : bid / G::TILES;
     if (tid < 512) reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
-    p2_tile<DIR, W, AUX_DEFAULT>(ring + t * (1ull << 20), dst + t * (1ull << 20), tile, scale, xch, twi, tid,
+    p2_tile<DIR, W, FWA_RING_LD_AUX>(ring + t * (1ull << 20), dst + t * (1ull << 20), tile, scale, xch, twi, tid,
                                  [] { __syncthreads(); });
 }
 
