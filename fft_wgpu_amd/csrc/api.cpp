@@ -410,8 +410,8 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
             ctx->chain_single_us = (int64_t)single;
             ctx->chain_pair_us = (int64_t)all;
         } else {
-            rejected.push_back(cand);
-            ++ctx->n_chain_rejects;
+            rejected.push_back(cand);  // destroyed below, also when a HIP call of the check failed
+            if (e == hipSuccess) ++ctx->n_chain_rejects;
         }
     }
     for (auto s : rejected) (void)hipStreamDestroy(s);
