@@ -10,6 +10,11 @@ Launch: `python bench.py --gpus N` starts its own N ranks (child processes, star
 GPU) when WORLD_SIZE is not set; under torchrun it uses the environment it is given.  It refuses to run with
 fewer visible devices than --gpus.
 
+Order of one run (rank 0, N = 1): the CPU baseline first (the oracle's restatement of the reference algorithm on the host
+cores, ~12 s, nothing on the GPU yet), then the GPU phase -- warm-up, the K timed steps, the stream-ceiling calibration
+and a 100-exec spread leg (HIP events only, not part of `value`); the line carries "gpu_phase_s", the wall time of
+that phase, so that a utilisation sampler's window can be compared with it.
+
 Timing: K steps inside barrier + torch.cuda.synchronize() brackets, wall clock, MAX over ranks.
 Because a forward FFT multiplies the RMS by 2^10 and `proc` works in place, the K steps run in
 chunks of <= 8 with the input regenerated (at scale 2^-40) between chunks, outside the brackets,
@@ -77,6 +82,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="override plan tunable (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--spread", type=int, default=100, help="extra execs timed one by one after the K steps (0 = off)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -105,6 +111,19 @@ def main():
 
     import fft_wgpu_amd as fw
     from fft_wgpu_amd import sharding
+
+    # CPU baseline BEFORE anything runs on the GPU (rank 0, N = 1 only): afterwards the run is one contiguous GPU phase
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
+        cores = usable_cores()
+        cb = max(cores, 8)
+        sps, reps = oracle.bench_forward(args.fft_len, cb, threads=cores, min_seconds=args.cpu_seconds)
+        cpu = {"value": sps / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": "port",
+               "sample": f"{cb} transforms of N={args.fft_len} (same generator, seed 0x5EED), best of {reps} repetitions, "
+                         f"OpenMP over transforms; CPU restatement of the reference radix-2 Stockham algorithm; timed "
+                         f"before the GPU phase"}
+    t_gpu_phase = time.perf_counter()
 
     got = fw.prepare_gpu(local_rank)
     if got is None:
@@ -159,30 +178,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
-    # calibration: float4 copy of 8 GiB (read + write) on the same stream, same run
-    copy_gbps = None
+    # calibration on the same stream, same run (rank 0): what a single streaming pass sustains on this box --
+    #  * in place (every line read, then written back: the traffic of the one-launch FFT kernels; fwa_calib_copy with
+    #    dst == src runs the normalize kernel's shape: 32-KiB chunk per workgroup, 16 nt loads in flight per thread),
+    #  * out of place (8 GiB -> another 8 GiB: one workgroup per 64-KiB chunk, nt).
+    copy_gbps = stream_gbps = None
+    spread = single_pass = None
     if rank == 0:
+        def rate(dst, src, nb, reps=3):
+            dev.calib_copy(dst, src, nb, encoder=enc)
+            a, b = fw.Event(dev), fw.Event(dev)
+            a.record(enc)
+            for _ in range(reps):
+                dev.calib_copy(dst, src, nb, encoder=enc)
+            b.record(enc)
+            return reps * 2 * nb / (a.elapsed_ms(b) * 1e-3) / 1e9
         half = min(nbytes // 2, 8 << 30) // 16 * 16
         if half >= (1 << 20):
             src_view = dev.wrap_buffer(buf.device_ptr, half)
             dst_view = dev.wrap_buffer(buf.device_ptr + half, half)
-            dev.calib_copy(dst_view, src_view, half, encoder=enc)
+            copy_gbps = rate(dst_view, src_view, half)
+            whole = dev.wrap_buffer(buf.device_ptr, 2 * half)
+            stream_gbps = rate(whole, whole, 2 * half)
+        # what a ONE-pass transform reaches on this box in this run: n = 1024 over the same 32 GiB (16 B/sample cross the
+        # fabric once; the 2^20 transform needs two passes = 32 B/sample)
+        if n > 1024 and nbytes % (1024 * 8) == 0:
+            regen()
+            small = fw.Forward(dev, queue, buf, 1024)
+            small.proc(enc)
             a, b = fw.Event(dev), fw.Event(dev)
             a.record(enc)
-            for _ in range(3):
-                dev.calib_copy(dst_view, src_view, half, encoder=enc)
+            for _ in range(2):
+                small.proc(enc)
             b.record(enc)
-            copy_gbps = 3 * 2 * half / (a.elapsed_ms(b) * 1e-3) / 1e9
-
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
-        cores = usable_cores()
-        cb = max(cores, 8)
-        sps, reps = oracle.bench_forward(n, cb, threads=cores, min_seconds=args.cpu_seconds)
-        cpu = {"value": sps / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": "port",
-               "sample": f"{cb} transforms of N={n} (same generator, seed 0x5EED), best of {reps} repetitions, "
-                         f"OpenMP over transforms; CPU restatement of the reference radix-2 Stockham algorithm"}
+            ms1 = a.elapsed_ms(b) / 2
+            single_pass = {"fft_len": 1024, "batch": nbytes // 8 // 1024, "ms": ms1,
+                           "GBps": ALGO_BYTES_PER_SAMPLE * (nbytes // 8) / (ms1 * 1e-3) / 1e9,
+                           "frac": ALGO_BYTES_PER_SAMPLE * (nbytes // 8) / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            small.destroy()
+        # spread leg: `args.spread` more execs timed one by one with HIP events (not part of `value`)
+        if args.spread > 0:
+            sp = []
+            done_s = 0
+            while done_s < args.spread:
+                k = min(CHUNK, args.spread - done_s)
+                regen()
+                evs = [(fw.Event(dev), fw.Event(dev)) for _ in range(k)]
+                for a, b in evs:
+                    a.record(enc)
+                    plan.proc(enc)
+                    b.record(enc)
+                enc.synchronize()
+                sp += [a.elapsed_ms(b) for a, b in evs]
+                done_s += k
+            sp.sort()
+            spread = {"execs": len(sp), "ms_p10": sp[len(sp) // 10], "ms_p50": sp[len(sp) // 2], "ms_p90": sp[(len(sp) * 9) // 10],
+                      "ms_min": sp[0], "ms_max": sp[-1]}
+    enc.synchronize()
+    gpu_phase_s = time.perf_counter() - t_gpu_phase
 
     if rank == 0:
         samples_per_step = n * batch * world
@@ -238,8 +291,14 @@ def main():
                                         "achieved_GBps_one_launch": launch_bytes / (avg_launch_us * 1e-6) / 1e9,
                                         "traffic_bytes": (traffic / launches) if traffic else None},
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
-                         "copy_ceiling_GBps_same_run": copy_gbps},
+                         # what ONE streaming pass over the data sustains in this run: in place (the one-launch FFT kernels'
+                         # traffic) and out of place; a two-pass transform moves 32 B/sample at about this rate
+                         "copy_ceiling_GBps_same_run": stream_gbps, "copy_ceiling_kind": "in-place read + write-back of 16 GiB, one workgroup per 32-KiB chunk, 16 nt 8-byte loads in flight per thread",
+                         "copy_out_of_place_GBps_same_run": copy_gbps,
+                         "single_pass_reference_same_run": single_pass,
+                         "exec_spread_hip_events": spread},
             "cpu_baseline": cpu,
+            "gpu_phase_s": gpu_phase_s,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

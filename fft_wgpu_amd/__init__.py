@@ -5,9 +5,10 @@ Normalize :: new, proc).  Hand-written HIP for gfx950 behind a C ABI
 """
 from ._ffi import FwaError, LIB_PATH  # noqa: F401
 from .device import (Buffer, CommandEncoder, Device, Event, Queue, device_count,  # noqa: F401
-                     prepare_gpu)
+                     enumerate_adapters, prepare_gpu)
 from .pipeline import HostPipeline  # noqa: F401
 from .processor import Forward, Inverse, Normalize, Onlyinverse  # noqa: F401
+from .sharding import Comm, ShardedBatch, slab  # noqa: F401
 
 COMPLEX_BYTES = 8  # src/lib.rs:10-15: {real: f32, imag: f32}
 

@@ -39,10 +39,14 @@ _SIGNATURES = {
     "fwa_last_error_string": (ctypes.c_char_p, [_P]),
     "fwa_status_string": (ctypes.c_char_p, [_I32]),
     "fwa_device_count": (_I32, [ctypes.POINTER(_I32)]),
+    "fwa_device_info": (_I32, [_I32, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_I32), ctypes.POINTER(_U64),
+                               ctypes.POINTER(_I32)]),
     "fwa_ctx_create": (_I32, [_I32, _PP]),
     "fwa_ctx_destroy": (_I32, [_P]),
     "fwa_ctx_synchronize": (_I32, [_P]),
     "fwa_ctx_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "fwa_ctx_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
+    "fwa_ctx_peer_access": (_I32, [_P, _P, ctypes.POINTER(_I32)]),
     "fwa_ctx_device_info": (_I32, [_P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_I32),
                                    ctypes.POINTER(_U64)]),
     "fwa_stream_create": (_I32, [_P, _PP]),
@@ -67,6 +71,14 @@ _SIGNATURES = {
     "fwa_describe_path": (_I32, [_U32, ctypes.POINTER(_I32), ctypes.POINTER(_U32 * 3)]),
     "fwa_plan_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "fwa_plan_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
+    "fwa_slab": (_I32, [_U64, _I32, _I32, ctypes.POINTER(_U64), ctypes.POINTER(_U64)]),
+    "fwa_comm_unique_id": (_I32, [ctypes.c_char_p]),
+    "fwa_comm_create": (_I32, [_P, ctypes.c_char_p, _I32, _I32, _PP]),
+    "fwa_comm_destroy": (_I32, [_P]),
+    "fwa_comm_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "fwa_comm_sendrecv": (_I32, [_P, _P, _U64, _U64, _I32, _P, _U64, _U64, _I32, _P]),
+    "fwa_comm_scatter": (_I32, [_P, _I32, _P, _P, _U32, _U64, _P]),
+    "fwa_comm_gather": (_I32, [_P, _I32, _P, _P, _U32, _U64, _P]),
     "fwa_event_create": (_I32, [_P, _PP]),
     "fwa_event_record": (_I32, [_P, _P]),
     "fwa_event_synchronize": (_I32, [_P]),

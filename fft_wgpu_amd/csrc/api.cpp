@@ -22,6 +22,7 @@
 #include <tuple>
 #include <vector>
 
+#include "internal.h"
 #include "kernels.h"
 
 using fwa::v2f;
@@ -81,7 +82,10 @@ struct fwa_ctx {
     // creation to run kernels side by side (chain_streams() below).
     std::vector<hipStream_t> chains;
     std::vector<hipStream_t> user_streams;  // alive streams made by fwa_stream_create, oldest first
+    std::vector<fwa_stream *> live_streams; // every alive fwa_stream handle of this context (created or wrapped)
     int64_t n_chain_checks = 0, n_chain_rejects = 0, chain_pair_us = 0, chain_single_us = 0;
+    int64_t chain_check = 1;                // fwa_ctx_set_i64("chain_check", 0): new streams are taken as the runtime hands them out
+    std::vector<int> peers_enabled;         // device ordinals this context's device has peer access to (enabled once)
 };
 struct fwa_stream {
     fwa_ctx *ctx = nullptr;
@@ -141,6 +145,7 @@ struct fwa_plan {
     int64_t wgs = 512;             // persistent workgroups (2 per CU)
     // L2-resident team pipeline (PATH_TEAM)
     int64_t max_teams = 0;         // teams (= slabs) per XCD; 0 = as many as fit 3 MiB of an XCD's 4-MiB L2
+    int64_t inject_fail_group = -1;  // laboratory: the launch of this group fails once (error path of run_groups under test)
 };
 
 namespace {
@@ -359,17 +364,45 @@ void destroy_pipeline_objects(fwa_ctx *ctx, Pipeline &pl, bool pool_ring)
 // kernel on its `peers` (time on all of them at once < single + half a spin); a rejected candidate stays alive until the
 // search ends so that the runtime cannot hand the same queue back.  Best effort: after 6 rejections the last candidate is
 // kept (a process with more streams than the runtime has hardware queues cannot overlap them all).
+//
+// Side effects, and how a caller controls them (include/fft_wgpu_amd.h, "Threading"): the check launches ~40-us spin
+// kernels on the candidate, on the peers and on a private base stream of its own -- never on the null stream -- and runs
+// only when there are peers to overlap with (a plan with one chain, or a context's first stream, costs nothing).  It is
+// refused with FWA_ERR_UNSUPPORTED while a stream of this context is capturing a graph (its timing would be meaningless and
+// the peers may be the capturing streams), and fwa_ctx_set_i64(ctx, "chain_check", 0) turns it off: streams are then taken
+// as the runtime hands them out.
+bool any_stream_capturing(const fwa_ctx *ctx)
+{
+    for (const fwa_stream *s : ctx->live_streams) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (s->s && hipStreamIsCapturing(s->s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return true;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+
 int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, hipStream_t *out)
 {
     *out = nullptr;
+    if (peers.empty() || !ctx->chain_check) {
+        hipError_t ce = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        if (ce != hipSuccess) { *out = nullptr; return fail_hip(ctx, ce, "hipStreamCreateWithFlags"); }
+        return FWA_OK;
+    }
+    if (any_stream_capturing(ctx))
+        return fail(ctx, FWA_ERR_UNSUPPORTED,
+                    "a stream of this context is capturing a graph: create plans and streams before the capture begins, or "
+                    "turn the stream-overlap check off with fwa_ctx_set_i64(ctx, \"chain_check\", 0)");
     constexpr uint32_t TICKS = 4000, BLOCKS = 256;  // 40 us, one wave per CU
     hipEvent_t e0 = nullptr, e1 = nullptr, fork = nullptr;
+    hipStream_t base = nullptr;  // the check's own fork / join stream: nothing here touches the null stream
     std::vector<hipEvent_t> done;
     std::vector<hipStream_t> rejected;
-    hipError_t e = hipEventCreate(&e0);
+    hipError_t e = hipStreamCreateWithFlags(&base, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-    auto timed = [&](const std::vector<hipStream_t> &set, float *us) {  // spin on every stream of `set`, forked from / joined to the null stream
+    auto timed = [&](const std::vector<hipStream_t> &set, float *us) {  // spin on every stream of `set`, forked from / joined to `base`
         float best = 1e30f;
         for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
             while (done.size() < set.size() && e == hipSuccess) {
@@ -377,15 +410,15 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
                 e = hipEventCreateWithFlags(&d, hipEventDisableTiming);
                 if (e == hipSuccess) done.push_back(d);
             }
-            if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-            if (e == hipSuccess) e = hipEventRecord(fork, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e0, base);
+            if (e == hipSuccess) e = hipEventRecord(fork, base);
             for (size_t i = 0; i < set.size() && e == hipSuccess; ++i) {
                 e = hipStreamWaitEvent(set[i], fork, 0);
                 if (e == hipSuccess) e = fwa::launch_spin(TICKS, BLOCKS, set[i]);
                 if (e == hipSuccess) e = hipEventRecord(done[i], set[i]);
-                if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, done[i], 0);
+                if (e == hipSuccess) e = hipStreamWaitEvent(base, done[i], 0);
             }
-            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e1, base);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             float ms = 0;
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
@@ -397,7 +430,6 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
         hipStream_t cand = nullptr;
         e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
         if (e != hipSuccess) break;
-        if (peers.empty()) { *out = cand; break; }
         std::vector<hipStream_t> set = peers;
         set.push_back(cand);
         float single = 0, all = 0;
@@ -417,6 +449,7 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
     for (auto s : rejected) (void)hipStreamDestroy(s);
     for (auto d : done) (void)hipEventDestroy(d);
     for (auto ev : {e0, e1, fork}) if (ev) (void)hipEventDestroy(ev);
+    if (base) (void)hipStreamDestroy(base);
     if (e != hipSuccess) return fail_hip(ctx, e, "stream setup");
     return FWA_OK;
 }
@@ -670,17 +703,24 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
     for (uint64_t g = 0; g < n_groups && e == hipSuccess; ++g) {
         const size_t c = ns ? (size_t)(g % ns) : 0;
         const uint64_t cnt = (plan->batch - g * G < G) ? plan->batch - g * G : G;
+#ifdef FWA_LAB
+        if (plan->inject_fail_group == (int64_t)g) { plan->inject_fail_group = -1; e = hipErrorLaunchFailure; break; }
+#endif
         e = body(g, cnt, ns ? plan->istreams[c] : st, c);
     }
-    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
-    if (ns) {
-        for (size_t i = 0; i < ns; ++i) {
-            HIP_TRY(ctx, hipEventRecord(plan->idone[i], plan->istreams[i]));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->idone[i], 0));
-        }
+    // Join the chains back to the caller's stream ALSO when a launch failed: the groups enqueued before the failure keep
+    // running on the chains, and whatever the caller enqueues next on `st` (a copy of the partial result, the free of the
+    // buffer) must be ordered behind them.
+    hipError_t je = hipSuccess;
+    for (size_t i = 0; i < ns; ++i) {
+        hipError_t r = hipEventRecord(plan->idone[i], plan->istreams[i]);
+        if (r == hipSuccess) r = hipStreamWaitEvent(st, plan->idone[i], 0);
+        if (r != hipSuccess && je == hipSuccess) je = r;
     }
     plan->last_stream = st;
     plan->ran_on_stream = true;
+    if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
+    if (je != hipSuccess) return fail_hip(ctx, je, "hipEventRecord/hipStreamWaitEvent (join of the chain streams)");
     return FWA_OK;
 }
 
@@ -716,6 +756,45 @@ int32_t fwa_device_count(int32_t *count)
         return fail_hip(nullptr, e, "hipGetDeviceCount", FWA_ERR_NO_DEVICE);
     }
     *count = n;
+    return FWA_OK;
+}
+
+int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int32_t *compute_units, uint64_t *hbm_bytes,
+                        int32_t *usable)
+{
+    if (name && name_cap) name[0] = 0;
+    if (compute_units) *compute_units = 0;
+    if (hbm_bytes) *hbm_bytes = 0;
+    if (usable) *usable = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, FWA_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, FWA_ERR_INVALID_ARG, "device ordinal out of range");
+    hipDeviceProp_t prop{};
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
+    if (name && name_cap) {
+        std::strncpy(name, prop.gcnArchName, name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (usable) *usable = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    return FWA_OK;
+}
+
+// The slab rule of SURVEY.md 8(e): contiguous runs of whole transforms, sizes differing by at most one.  Pure host logic;
+// fft_wgpu_amd/sharding.py::slab and fft_wgpu::slab (include/fft_wgpu.hpp) are this function.
+int32_t fwa_slab(uint64_t batch, int32_t rank, int32_t world, uint64_t *first, uint64_t *count)
+{
+    if (!first || !count) return fail(nullptr, FWA_ERR_INVALID_ARG, "first/count is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FWA_ERR_INVALID_ARG, "bad rank / world size");
+    const uint64_t base = batch / (uint64_t)world, extra = batch % (uint64_t)world, r = (uint64_t)rank;
+    *first = r * base + (r < extra ? r : extra);
+    *count = base + (r < extra ? 1 : 0);
     return FWA_OK;
 }
 
@@ -785,6 +864,8 @@ int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
     else if (k == "chain_rejects") *value = ctx->n_chain_rejects;
     else if (k == "chain_pair_us") *value = ctx->chain_pair_us;
     else if (k == "chain_single_us") *value = ctx->chain_single_us;
+    else if (k == "chain_check") *value = ctx->chain_check;
+    else if (k == "live_streams") *value = (int64_t)ctx->live_streams.size();
     else if (k == "mem_free_bytes" || k == "mem_total_bytes") {
         int cur = -1;
         size_t fr = 0, tot = 0;
@@ -794,6 +875,20 @@ int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
     }
     else return fail(ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
     return FWA_OK;
+}
+
+int32_t fwa_ctx_set_i64(fwa_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return fail(ctx, FWA_ERR_INVALID_ARG, "NULL argument");
+    const std::string k(key);
+    if (k == "chain_check") {
+        // 0: streams this library creates (the chain streams of pipelined plans, fwa_stream_create) are no longer tested
+        // for overlap with spin kernels (overlapping_stream above)
+        if (value != 0 && value != 1) return fail(ctx, FWA_ERR_INVALID_ARG, "chain_check is 0 or 1");
+        ctx->chain_check = value;
+        return FWA_OK;
+    }
+    return fail(ctx, FWA_ERR_INVALID_ARG, "unknown or read-only key: " + k);
 }
 
 int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap, int32_t *compute_units,
@@ -826,6 +921,7 @@ int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
     if (!st) { (void)hipStreamDestroy(s); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     st->ctx = ctx; st->s = s; st->owned = true;
     ctx->user_streams.push_back(s);
+    ctx->live_streams.push_back(st);
     *out = st;
     return FWA_OK;
 }
@@ -836,6 +932,7 @@ int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out)
     fwa_stream *st = new (std::nothrow) fwa_stream;
     if (!st) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
     st->ctx = ctx; st->s = reinterpret_cast<hipStream_t>(hip_stream); st->owned = false;
+    ctx->live_streams.push_back(st);
     *out = st;
     return FWA_OK;
 }
@@ -851,6 +948,10 @@ int32_t fwa_stream_synchronize(fwa_stream *stream)
 int32_t fwa_stream_destroy(fwa_stream *stream)
 {
     if (!stream) return FWA_OK;
+    {
+        auto &ls = stream->ctx->live_streams;
+        ls.erase(std::remove(ls.begin(), ls.end(), stream), ls.end());
+    }
     if (stream->owned) {
         (void)hipSetDevice(stream->ctx->device);
         auto &us = stream->ctx->user_streams;
@@ -926,6 +1027,35 @@ int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, ui
     return FWA_OK;
 }
 
+// Peer reachability of two contexts' devices.  kind: 0 = none (stage through the host or use fwa_comm_*), 1 = the same
+// device, 2 = peer access (xGMI or PCIe peer-to-peer), enabled on first use in both directions.
+static int32_t peer_kind(fwa_ctx *a, fwa_ctx *b, int32_t *kind)
+{
+    *kind = 0;
+    if (a->device == b->device) { *kind = 1; return FWA_OK; }
+    int ab = 0, ba = 0;
+    HIP_TRY(a, hipDeviceCanAccessPeer(&ab, a->device, b->device));
+    HIP_TRY(a, hipDeviceCanAccessPeer(&ba, b->device, a->device));
+    if (!ab || !ba) return FWA_OK;
+    for (fwa_ctx *c : {a, b}) {
+        fwa_ctx *o = c == a ? b : a;
+        if (std::find(c->peers_enabled.begin(), c->peers_enabled.end(), o->device) != c->peers_enabled.end()) continue;
+        HIP_TRY(c, hipSetDevice(c->device));
+        hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail_hip(c, e, "hipDeviceEnablePeerAccess");
+        (void)hipGetLastError();
+        c->peers_enabled.push_back(o->device);
+    }
+    *kind = 2;
+    return FWA_OK;
+}
+
+int32_t fwa_ctx_peer_access(fwa_ctx *ctx, fwa_ctx *peer, int32_t *kind)
+{
+    if (!ctx || !peer || !kind) return fail(ctx, FWA_ERR_INVALID_ARG, "NULL argument");
+    return peer_kind(ctx, peer, kind);
+}
+
 int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint64_t src_offset, uint64_t bytes,
                      fwa_stream *stream)
 {
@@ -933,11 +1063,28 @@ int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint
     if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset || src_offset > src->bytes ||
         bytes > src->bytes - src_offset)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy range exceeds buffer");
+    if (stream && stream->ctx != dst->ctx && stream->ctx != src->ctx)
+        return fail(dst->ctx, FWA_ERR_INVALID_ARG, "the stream belongs to neither buffer's context");
     if (!bytes) return FWA_OK;
-    USE_DEVICE(dst->ctx);
-    HIP_TRY(dst->ctx, hipMemcpyAsync(static_cast<char *>(dst->p) + dst_offset,
-                                     static_cast<const char *>(src->p) + src_offset, bytes, hipMemcpyDeviceToDevice,
-                                     raw(stream)));
+    char *d = static_cast<char *>(dst->p) + dst_offset;
+    const char *s = static_cast<const char *>(src->p) + src_offset;
+    fwa_ctx *on = stream ? stream->ctx : dst->ctx;  // the copy is enqueued on a stream of this context's device
+    if (dst->ctx->device == src->ctx->device) {
+        USE_DEVICE(on);
+        HIP_TRY(on, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, raw(stream)));
+        return FWA_OK;
+    }
+    // two devices (one process driving several contexts: SURVEY.md 8(e)): an explicit peer copy, or a status code -- never a
+    // pointer the current device cannot reach handed to a plain device-to-device copy
+    int32_t kind = 0;
+    int32_t st = peer_kind(dst->ctx, const_cast<fwa_ctx *>(src->ctx), &kind);
+    if (st) return st;
+    if (kind != 2)
+        return fail(dst->ctx, FWA_ERR_UNSUPPORTED,
+                    "devices " + std::to_string(src->ctx->device) + " and " + std::to_string(dst->ctx->device) +
+                        " have no peer access: stage through the host (fwa_buf_download / fwa_buf_upload) or move the slab with fwa_comm_*");
+    USE_DEVICE(on);
+    HIP_TRY(on, hipMemcpyPeerAsync(d, dst->ctx->device, s, src->ctx->device, bytes, raw(stream)));
     return FWA_OK;
 }
 
@@ -1331,6 +1478,13 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (value < 1 || value > (k == "streams" ? 16 : 4096)) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         return build_pipeline(plan, k == "group" ? value : plan->group, k == "streams" ? value : plan->n_streams);
     }
+    if (k == "inject_launch_failure") {
+        // laboratory: the launch of group `value` fails once (nothing is enqueued for it): the error path of run_groups
+        if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "inject_launch_failure is a laboratory knob (libfft_wgpu_amd_lab.so)");
+        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths");
+        plan->inject_fail_group = value;
+        return FWA_OK;
+    }
     if (k == "ring_rotate") {
         if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "ring_rotate is a laboratory knob (libfft_wgpu_amd_lab.so)");
         if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
@@ -1541,9 +1695,26 @@ int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_str
     if (bytes > dst->bytes || bytes > src->bytes || (bytes & 15))
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
     USE_DEVICE(dst->ctx);
-    hipError_t e = fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
+    // dst == src: an in-place streaming pass (every line read, then written back) -- the normalize kernel with scale 1:
+    // 32-KiB chunk per workgroup, 16 nt loads in flight per thread, the traffic pattern of the one-launch FFT kernels
+    hipError_t e = (dst->p == src->p) ? fwa::launch_scale(static_cast<const v2f *>(src->p), static_cast<v2f *>(dst->p), bytes / 8, 1.0f, raw(stream))
+                                      : fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
     if (e != hipSuccess) return fail_hip(dst->ctx, e, "copy launch", FWA_ERR_LAUNCH);
     return FWA_OK;
 }
 
 }  // extern "C"
+
+namespace fwa_int {
+int32_t fail(const fwa_ctx *ctx, int32_t status, const std::string &msg) { return ::fail(ctx, status, msg); }
+int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what) { return ::fail_hip(ctx, e, what); }
+int32_t use_device(fwa_ctx *ctx)
+{
+    USE_DEVICE(ctx);
+    return FWA_OK;
+}
+int ctx_device(const fwa_ctx *ctx) { return ctx->device; }
+fwa_ctx *buf_ctx(const fwa_buf *b) { return b->ctx; }
+hipStream_t stream_raw(fwa_stream *s) { return s ? s->s : nullptr; }
+fwa_ctx *stream_ctx(fwa_stream *s) { return s ? s->ctx : nullptr; }
+}  // namespace fwa_int

@@ -122,21 +122,21 @@ hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st)
     return hipGetLastError();
 }
 
-// Calibration copy, shaped like the one-launch FFT kernels: one workgroup per contiguous 64-KiB chunk, every thread
-// issues its 16 non-temporal 16-byte loads before the first store (256 KiB in flight per CU at four workgroups).  A
-// plain grid-stride float4 copy reaches 4.7-5.0 TB/s on this part, this shape 6 TB/s and more (the 6.29 TB/s of
-// MI355X_MICROARCH.md): profiles/round2/probe_copy_shapes.txt.
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// Calibration copy, shaped like the one-launch FFT kernels: one workgroup per contiguous 32-KiB chunk, every thread
+// issues its 16 non-temporal 8-byte loads (one complex sample each, as every FFT kernel does) before the first store.
+// tools/stream_probe.hip (profiles/round4/probe_stream_shapes.txt) compares lanes of 8 / 16 bytes x 8 / 16 / 32 accesses
+// per thread, in and out of place: 5.5-5.9 TB/s all of them, this shape on top; a grid-stride float4 loop with default
+// policy reaches 4.7-5.0 (profiles/round2/probe_copy_shapes.txt).
 __global__ __launch_bounds__(256) void k_copy(const char *__restrict__ a, char *__restrict__ b, uint64_t n_chunks)
 {
-    constexpr uint32_t CHUNK = 65536, U = 16;
+    constexpr uint32_t CHUNK = 32768, U = 16;
     const uint64_t c = blockIdx.x;
     if (c >= n_chunks) return;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * CHUNK, 0, CHUNK, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * CHUNK, 0, CHUNK, 0x00020000);
-    v4u x[U];
-    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, threadIdx.x * 16, i * 4096, AUX_NT); });
-    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; __builtin_amdgcn_raw_buffer_store_b128(x[i], rb, threadIdx.x * 16, i * 4096, AUX_NT); });
+    v2u x[U];
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = __builtin_amdgcn_raw_buffer_load_b64(ra, threadIdx.x * 8, i * 2048, AUX_NT); });
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, threadIdx.x * 8, i * 2048, AUX_NT); });
 }
 
 __global__ __launch_bounds__(256) void k_copy_tail(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t first, uint64_t n_vec)
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256) void k_copy_tail(const v4f *__restrict__ a, v4
 
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st)
 {
-    const uint64_t n_chunks = bytes / 65536, n_vec = bytes / 16;
+    const uint64_t n_chunks = bytes / 32768, n_vec = bytes / 16;
     if (n_vec == 0) return hipSuccess;
     if (n_chunks > 0x7fffffffull) return hipErrorInvalidValue;
     if (n_chunks)
         hipLaunchKernelGGL(k_copy, dim3((uint32_t)n_chunks), dim3(256), 0, st, static_cast<const char *>(src),
                            static_cast<char *>(dst), n_chunks);
-    const uint64_t done = n_chunks * 4096;  // 16-byte vectors copied by the chunk kernel
+    const uint64_t done = n_chunks * 2048;  // 16-byte vectors copied by the chunk kernel
     if (n_vec > done)
         hipLaunchKernelGGL(k_copy_tail, dim3((uint32_t)((n_vec - done + 255) / 256)), dim3(256), 0, st,
                            static_cast<const v4f *>(src), static_cast<v4f *>(dst), done, n_vec);

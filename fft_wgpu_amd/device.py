@@ -201,6 +201,21 @@ class Device:
             out[k] = v.value
         return out
 
+    def set(self, key, value):
+        """fwa_ctx_set_i64: "chain_check" = 0 turns the stream-overlap check of this context off."""
+        _ffi.check(self._L.fwa_ctx_set_i64(self._h, key.encode(), int(value)), self._h, "fwa_ctx_set_i64", self._L)
+
+    def get(self, key):
+        v = ctypes.c_int64()
+        _ffi.check(self._L.fwa_ctx_get_i64(self._h, key.encode(), ctypes.byref(v)), self._h, "fwa_ctx_get_i64", self._L)
+        return v.value
+
+    def peer_access(self, other):
+        """0: the two devices cannot reach each other, 1: same device, 2: peer access (enabled by this call)."""
+        k = ctypes.c_int32()
+        _ffi.check(self._L.fwa_ctx_peer_access(self._h, other._h, ctypes.byref(k)), self._h, "fwa_ctx_peer_access", self._L)
+        return k.value
+
     def pinned_array(self, n_elements, dtype=np.complex64):
         """Page-locked host staging array (the reference's MAP_READ staging buffer, examples/basic.rs:50-55)."""
         nbytes = int(n_elements) * np.dtype(dtype).itemsize
@@ -235,6 +250,21 @@ def device_count():
     n = ctypes.c_int32()
     st = _ffi.lib().fwa_device_count(ctypes.byref(n))
     return n.value if st == 0 else 0
+
+
+def enumerate_adapters():
+    """instance.enumerate_adapters(..) (src/lib.rs:33-35): one entry per visible device ordinal, without creating a
+    context: {"ordinal", "name", "compute_units", "hbm_bytes", "usable"} (usable = Device(ordinal) would succeed)."""
+    L = _ffi.lib()
+    out = []
+    for o in range(device_count()):
+        name = ctypes.create_string_buffer(256)
+        cus, mem, ok = ctypes.c_int32(), ctypes.c_uint64(), ctypes.c_int32()
+        _ffi.check(L.fwa_device_info(o, name, 256, ctypes.byref(cus), ctypes.byref(mem), ctypes.byref(ok)), None,
+                   "fwa_device_info", L)
+        out.append({"ordinal": o, "name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value,
+                    "usable": bool(ok.value)})
+    return out
 
 
 def prepare_gpu(ordinal=0, lab=False):

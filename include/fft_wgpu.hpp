@@ -11,6 +11,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fft_wgpu_amd.h"
@@ -27,13 +28,53 @@ public:
     int32_t status;
 };
 
+// wgpu::AdapterInfo of one device ordinal (instance.enumerate_adapters(..), lib.rs:33-35)
+struct AdapterInfo {
+    int ordinal = 0;
+    std::string name;         // gcnArchName
+    int32_t compute_units = 0;
+    uint64_t hbm_bytes = 0;
+    bool usable = false;      // Device(ordinal) would succeed (gfx950)
+};
+
+// One entry per visible device ordinal, no context created.  Empty when no device is visible (prepare_gpu -> None).
+inline std::vector<AdapterInfo> enumerate_devices()
+{
+    std::vector<AdapterInfo> out;
+    int32_t n = 0;
+    if (fwa_device_count(&n) != FWA_OK) return out;
+    for (int32_t o = 0; o < n; ++o) {
+        char name[256];
+        AdapterInfo a;
+        int32_t ok = 0;
+        int32_t st = fwa_device_info(o, name, sizeof name, &a.compute_units, &a.hbm_bytes, &ok);
+        if (st) throw Error(st, std::string("fwa_device_info: ") + fwa_last_error_string(nullptr));
+        a.ordinal = o; a.name = name; a.usable = ok != 0;
+        out.push_back(a);
+    }
+    return out;
+}
+
+// The slab rule: rank r of `world` owns transforms [first, first + count); = fwa_slab = sharding.slab.
+struct Slab {
+    uint64_t first = 0, count = 0;
+};
+inline Slab slab(uint64_t batch, int rank, int world)
+{
+    Slab s;
+    int32_t st = fwa_slab(batch, rank, world, &s.first, &s.count);
+    if (st) throw Error(st, std::string("fwa_slab: ") + fwa_last_error_string(nullptr));
+    return s;
+}
+
 class Device {  // wgpu::Device (+ Instance/Adapter/Queue), lib.rs:29-62
 public:
-    explicit Device(int ordinal = 0)
+    explicit Device(int ordinal = 0) : ordinal_(ordinal)
     {
         int32_t st = fwa_ctx_create(ordinal, &h_);
         if (st) throw Error(st, std::string("fwa_ctx_create: ") + fwa_last_error_string(nullptr));
     }
+    int ordinal() const { return ordinal_; }
     ~Device() { fwa_ctx_destroy(h_); }
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;
@@ -44,6 +85,7 @@ public:
     }
 
 private:
+    int ordinal_ = 0;
     fwa_ctx *h_ = nullptr;
 };
 using Queue = Device;  // the reference passes both (&device, &queue); one context plays both roles here
@@ -118,6 +160,19 @@ public:
     void copy_to(Buffer &dst, uint64_t bytes, CommandEncoder &e) const  // encoder.copy_buffer_to_buffer (basic.rs:84-90)
     {
         d_->check(fwa_buf_copy(dst.raw(), 0, h_, 0, bytes, e.raw()), "fwa_buf_copy");
+    }
+    // the five-argument form of copy_buffer_to_buffer; `dst` may live on another device (peer copy, fwa_buf_copy)
+    void copy_to(Buffer &dst, uint64_t dst_offset, uint64_t src_offset, uint64_t bytes, CommandEncoder &e) const
+    {
+        e.device().check(fwa_buf_copy(dst.raw(), dst_offset, h_, src_offset, bytes, e.raw()), "fwa_buf_copy");
+    }
+    void write_at(uint64_t offset, const void *host, uint64_t bytes, CommandEncoder *e = nullptr)
+    {
+        d_->check(fwa_buf_upload(h_, offset, host, bytes, e ? e->raw() : nullptr), "fwa_buf_upload");
+    }
+    void read_at(void *host, uint64_t offset, uint64_t bytes, CommandEncoder &e) const  // blocking, stream-ordered on e
+    {
+        d_->check(fwa_buf_download(host, h_, offset, bytes, e.raw()), "fwa_buf_download");
     }
     void read(void *host, uint64_t bytes, CommandEncoder *e = nullptr) const  // map_async + poll + get_mapped_range
     {
@@ -237,6 +292,89 @@ private:
     std::vector<std::unique_ptr<detail::Plan>> plans_;
     std::vector<std::unique_ptr<Event>> e_ex_, e_down_;
     uint64_t it_ = 0;
+};
+
+// One batch sharded over several devices driven by ONE process (the Python twin is
+// fft_wgpu_amd.ShardedBatch).  Transforms are independent (kernel/fft4.wgsl:21-23), so shard i is simply a Device + a
+// CommandEncoder + a slab buffer + a plan of kind `PlanT` on ordinal `ordinals[i]`, and slab i = slab(batch, i, shards).
+// proc() enqueues every shard's transform and returns at once; synchronize() joins.  Nothing communicates during the
+// transform; scatter() / gather() move slabs from / to one buffer with peer copies (fwa_buf_copy across contexts) for callers
+// whose batch starts on one device, write() / read() move them from / to host memory, each device taking only its own slab.
+// `ordinals` empty = every visible device; an ordinal may repeat (two contexts on one device: what a one-GPU box can test).
+template <class PlanT>
+class ShardedBatch {
+public:
+    ShardedBatch(uint32_t fft_len, uint64_t batch, std::vector<int> ordinals = {}) : fft_len_(fft_len), batch_(batch)
+    {
+        if (ordinals.empty())
+            for (const AdapterInfo &a : enumerate_devices())
+                if (a.usable) ordinals.push_back(a.ordinal);
+        if (ordinals.empty()) throw Error(FWA_ERR_NO_DEVICE, "ShardedBatch: no usable device");
+        const int world = (int)ordinals.size();
+        for (int r = 0; r < world; ++r) {
+            dev_.emplace_back(new Device(ordinals[(size_t)r]));
+            enc_.emplace_back(new CommandEncoder(*dev_.back()));
+            slabs_.push_back(slab(batch, r, world));
+            buf_.emplace_back(new Buffer(*dev_.back(), slabs_.back().count * 8ull * fft_len));
+            if constexpr (std::is_constructible<PlanT, const Device &, const Queue &, Buffer &, Buffer &, uint32_t>::value) {
+                second_.emplace_back(new Buffer(*dev_.back(), slabs_.back().count * 8ull * fft_len));  // Onlyinverse / Normalize
+                plan_.emplace_back(new PlanT(*dev_.back(), *dev_.back(), *buf_.back(), *second_.back(), fft_len));
+            } else {
+                plan_.emplace_back(new PlanT(*dev_.back(), *dev_.back(), *buf_.back(), fft_len));
+            }
+            result_.push_back(buf_.back().get());
+        }
+    }
+    size_t shards() const { return dev_.size(); }
+    Slab slab_of(size_t i) const { return slabs_[i]; }
+    Device &device(size_t i) { return *dev_[i]; }
+    CommandEncoder &encoder(size_t i) { return *enc_[i]; }
+    Buffer &buffer(size_t i) { return *buf_[i]; }      // shard i's slab (input of the transform)
+    Buffer &result(size_t i) { return *result_[i]; }   // where shard i's output is after proc() (processor.rs:153-157)
+    // enqueue the transform of every slab on its device; returns without waiting
+    void proc()
+    {
+        for (size_t i = 0; i < dev_.size(); ++i) result_[i] = &plan_[i]->proc(*enc_[i]);
+    }
+    void synchronize()
+    {
+        for (auto &e : enc_) e->synchronize();
+    }
+    // host memory -> slabs (batch * fft_len samples) / results -> host memory
+    void write(const Complex *data)
+    {
+        for (size_t i = 0; i < dev_.size(); ++i)
+            if (slabs_[i].count) buf_[i]->write_at(0, data + slabs_[i].first * fft_len_, slabs_[i].count * 8ull * fft_len_, enc_[i].get());
+        synchronize();
+    }
+    void read(Complex *out)
+    {
+        for (size_t i = 0; i < dev_.size(); ++i)
+            if (slabs_[i].count) result_[i]->read_at(out + slabs_[i].first * fft_len_, 0, slabs_[i].count * 8ull * fft_len_, *enc_[i]);
+    }
+    // `full` (the whole batch, on any shard's device, complete before the call) -> every shard's slab buffer
+    void scatter(const Buffer &full)
+    {
+        for (size_t i = 0; i < dev_.size(); ++i)
+            if (slabs_[i].count) full.copy_to(*buf_[i], 0, slabs_[i].first * 8ull * fft_len_, slabs_[i].count * 8ull * fft_len_, *enc_[i]);
+    }
+    // every shard's result -> `full`, each copy ordered behind its shard's transform; waits for all of them
+    void gather(Buffer &full)
+    {
+        for (size_t i = 0; i < dev_.size(); ++i)
+            if (slabs_[i].count) result_[i]->copy_to(full, slabs_[i].first * 8ull * fft_len_, 0, slabs_[i].count * 8ull * fft_len_, *enc_[i]);
+        synchronize();
+    }
+
+private:
+    uint32_t fft_len_;
+    uint64_t batch_;
+    std::vector<std::unique_ptr<Device>> dev_;
+    std::vector<std::unique_ptr<CommandEncoder>> enc_;
+    std::vector<Slab> slabs_;
+    std::vector<std::unique_ptr<Buffer>> buf_, second_;
+    std::vector<std::unique_ptr<PlanT>> plan_;
+    std::vector<Buffer *> result_;
 };
 
 }  // namespace fft_wgpu

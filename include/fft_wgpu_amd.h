@@ -19,6 +19,17 @@
  * One in-flight fwa_plan_exec per plan (plans own scratch).  One ctx per
  * device ordinal; multi-GPU = one process (or one ctx) per device: every
  * entry point makes its context's device current before it touches HIP.
+ * Internal streams: the pipelined plans (2^20 two-pass, tiled) run their
+ * groups of transforms on up to "streams" chain streams that belong to the
+ * CONTEXT and are shared by all its plans: two plans executed on two caller
+ * streams of one context therefore serialise on the chains (each exec still
+ * forks from and joins to its own caller stream; results are unaffected).
+ * Give concurrent pipelines their own context.  Streams this library creates
+ * (the chains, fwa_stream_create) are checked to really overlap their peers
+ * with ~40-us spin kernels at creation -- only when there is a peer to overlap
+ * with, never on the null stream, refused (FWA_ERR_UNSUPPORTED) while a stream
+ * of the context captures a graph; fwa_ctx_set_i64(ctx, "chain_check", 0)
+ * turns the check off.
  *
  * Errors: every function returns an fwa_status (0 = ok).  Nothing aborts or
  * throws across the ABI.  fwa_last_error_string() gives detail.
@@ -33,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FWA_ABI_VERSION 2
+#define FWA_ABI_VERSION 3
 
 typedef enum fwa_status {
     FWA_OK = 0,
@@ -68,6 +79,11 @@ const char *fwa_status_string(int32_t status);
 
 /* ---- device / queue : replaces lib.rs:29-62, examples/basic.rs:6-30 ---- */
 int32_t fwa_device_count(int32_t *count);
+/* instance.enumerate_adapters(..) (lib.rs:33-35): describes ordinal 0 <= device_ordinal < fwa_device_count without
+ * creating a context.  name: gcnArchName, truncated to name_cap; *usable = 1 when fwa_ctx_create would accept the
+ * device (gfx950).  Any output pointer may be NULL. */
+int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int32_t *compute_units,
+                        uint64_t *hbm_bytes, int32_t *usable);
 int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out);
 int32_t fwa_ctx_destroy(fwa_ctx *ctx);
 /* device.poll(Maintain::wait()) (examples/basic.rs:106): returns once ALL work submitted to this device, on
@@ -79,6 +95,8 @@ int32_t fwa_ctx_synchronize(fwa_ctx *ctx);
  * "last_plan_create_us" (wall time of the most recent fwa_plan_create); "mem_free_bytes" / "mem_total_bytes"
  * (hipMemGetInfo of the context's device). */
 int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value);
+/* Settable: "chain_check" (1 default; 0 = streams this library creates are not tested for overlap: see Threading). */
+int32_t fwa_ctx_set_i64(fwa_ctx *ctx, const char *key, int64_t value);
 /* name: NUL-terminated gcnArchName ("gfx950:..."), truncated to name_cap. */
 int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap,
                             int32_t *compute_units, uint64_t *hbm_bytes);
@@ -102,8 +120,14 @@ int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint
                        fwa_stream *stream);
 int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes,
                          fwa_stream *stream);
+/* Device-to-device copy, stream-ordered on `stream` (a stream of dst's or src's context; NULL = the null stream of dst's
+ * device).  The two buffers may belong to contexts on DIFFERENT devices (one process driving several GPUs, SURVEY.md
+ * 8(e)): the copy is then an explicit peer copy over xGMI / PCIe, peer access being enabled on first use; devices that
+ * cannot reach each other give FWA_ERR_UNSUPPORTED (stage through the host, or use fwa_comm_*), never a wild pointer. */
 int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint64_t src_offset,
                      uint64_t bytes, fwa_stream *stream);
+/* *kind: 0 = the devices of the two contexts cannot reach each other, 1 = same device, 2 = peer access (enabled here). */
+int32_t fwa_ctx_peer_access(fwa_ctx *ctx, fwa_ctx *peer, int32_t *kind);
 /* Pinned (page-locked) host staging memory: with it fwa_buf_upload is truly asynchronous and
  * fwa_buf_download_async can overlap with transforms on another stream -- the reference's benchmark loop
  * (examples/basic.rs:72-127: write_buffer -> proc -> copy -> map) pipelined over three streams. */
@@ -173,7 +197,8 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  * fwa_ctx_get_i64: "device", "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "pooled_ring_bytes",
  * "last_plan_create_us", "mem_free_bytes", "mem_total_bytes", "chain_streams" (chain streams created so far),
  * "chain_checks" / "chain_rejects" (candidates tested / discarded because they did not overlap the other chains),
- * "chain_single_us" / "chain_pair_us" (the check's spin kernel alone / on all chains at once).
+ * "chain_single_us" / "chain_pair_us" (the check's spin kernel alone / on all chains at once), "chain_check",
+ * "live_streams" (alive fwa_stream handles of the context).
  *
  * Laboratory build only (fft_wgpu_amd/libfft_wgpu_amd_lab.so, `make -C fft_wgpu_amd/csrc lab`; the product library
  * answers FWA_ERR_UNSUPPORTED): kernel families that measured slower than the shipped ones, kept for A/B timing and
@@ -183,9 +208,45 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   7 <-> 8) with "max_teams", "wgs" (>= 8 x team size); "device_error" (paths 5, 8; synchronises the device; non-zero
  *   = a bounded in-kernel spin timed out); "tile_w" = 32 (2^20: 1024-thread workgroups, 256-byte segments);
  *   "small_reg" (n <= 32768: 1 = the shipped kernels; 3 = the direct-addressing 16-point kernels up to 4096; 2 = + the
- *   wavefront-shuffle exchange at 32 / 64 / 128; 0 = LDS radix-2 kernel up to 4096). */
+ *   wavefront-shuffle exchange at 32 / 64 / 128; 0 = LDS radix-2 kernel up to 4096); "inject_launch_failure" (pipelined
+ *   paths: the launch of that group fails once -- the error path of fwa_plan_exec under test). */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
+
+/* ---- multi-GPU: batch sharding (no reference analogue: the reference drives one device, one queue) ------------------
+ * Transforms are independent (kernel/fft4.wgsl:21-23: one `offset` per workgroup), so a batch shards as contiguous slabs
+ * of whole transforms, one slab per GPU, and the transform itself never communicates.
+ *
+ * fwa_slab: the slab rule -- rank r of `world` owns transforms [*first, *first + *count), counts differ by at most one
+ * (pure host logic, no device needed; fft_wgpu_amd/sharding.py::slab and fft_wgpu::slab are this function).
+ *
+ * Moving slabs when the batch starts on (or must return to) one GPU:
+ *  - ONE process driving several contexts holds every pointer: fwa_buf_copy between buffers of two contexts (peer copy);
+ *    fft_wgpu::ShardedBatch (include/fft_wgpu.hpp) and fft_wgpu_amd.ShardedBatch are built on it.
+ *  - one process PER GPU (torchrun-style deployment): fwa_comm_* below, grouped ncclSend / ncclRecv over RCCL (xGMI).
+ *    librccl is dlopen'ed on the first fwa_comm_* call; FWA_ERR_UNSUPPORTED if it cannot be loaded.
+ * fwa_comm_unique_id: rank 0 makes the id and hands the 128 bytes to the other ranks by any means (file, socket,
+ * torch.distributed store).  fwa_comm_create is collective over the `world` processes holding the same id, one rank per
+ * device.  Scatter / gather are collective too, stream-ordered on `stream` (a stream of the communicator's context):
+ *   scatter: root's `full` (batch transforms) -> every rank's `slab` (>= its count transforms); `full` is ignored elsewhere
+ *   gather : every rank's `slab` -> root's `full`
+ * fwa_comm_sendrecv: the primitive under both -- one send and/or one receive in one group (rank < 0 = none); sending to the
+ * own rank needs the matching receive in the same call (a ring shift of slabs is `sendrecv(to = r+1, from = r-1)`). */
+typedef struct fwa_comm fwa_comm;
+#define FWA_COMM_ID_BYTES 128
+int32_t fwa_slab(uint64_t batch, int32_t rank, int32_t world, uint64_t *first, uint64_t *count);
+int32_t fwa_comm_unique_id(uint8_t id[FWA_COMM_ID_BYTES]);
+int32_t fwa_comm_create(fwa_ctx *ctx, const uint8_t id[FWA_COMM_ID_BYTES], int32_t world, int32_t rank, fwa_comm **out);
+int32_t fwa_comm_destroy(fwa_comm *comm);
+/* Keys: "rank", "world", "device". */
+int32_t fwa_comm_get_i64(const fwa_comm *comm, const char *key, int64_t *value);
+int32_t fwa_comm_sendrecv(fwa_comm *comm, const fwa_buf *send, uint64_t send_offset, uint64_t send_bytes, int32_t send_to,
+                          fwa_buf *recv, uint64_t recv_offset, uint64_t recv_bytes, int32_t recv_from,
+                          fwa_stream *stream);
+int32_t fwa_comm_scatter(fwa_comm *comm, int32_t root, const fwa_buf *full_or_null, fwa_buf *slab, uint32_t fft_len,
+                         uint64_t batch, fwa_stream *stream);
+int32_t fwa_comm_gather(fwa_comm *comm, int32_t root, const fwa_buf *slab, fwa_buf *full_or_null, uint32_t fft_len,
+                        uint64_t batch, fwa_stream *stream);
 
 /* ---- measurement helpers (HIP events on the launch stream) -------------- */
 int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out);
@@ -204,7 +265,9 @@ int32_t fwa_event_destroy(fwa_event *ev);
  * in [-1,1) times `scale`.  Bit-identical to oracle/ref_fft.c:fwo_gen_input. */
 int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform,
                            uint32_t fft_len, float scale, fwa_stream *stream);
-/* float4 streaming copy of `bytes` from src to dst (the measured-ceiling calibration kernel). */
+/* Streaming copy of `bytes` from src to dst (the measured-ceiling calibration kernel: one workgroup per 64-KiB chunk, nt).
+ * With dst and src the SAME memory it is an in-place streaming pass instead -- every line read, then written back, in the
+ * launch shape of the one-launch FFT kernels -- the ceiling a single-pass transform is compared with. */
 int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_stream *stream);
 
 #ifdef __cplusplus

@@ -1,4 +1,4 @@
-// ffi.rs -- the `extern "C"` block over include/fft_wgpu_amd.h (ABI version 2).  UNVERIFIED: never compiled here (no
+// ffi.rs -- the `extern "C"` block over include/fft_wgpu_amd.h (ABI version 3).  UNVERIFIED: never compiled here (no
 // rustc in the image).  Generated from the header's prototypes; tests/test_abi.py checks that this list and the header
 // declare the same symbols.
 #![allow(non_camel_case_types, dead_code)]
@@ -9,9 +9,13 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct fwa_buf { _private: [u8; 0] }
 #[repr(C)] pub struct fwa_plan { _private: [u8; 0] }
 #[repr(C)] pub struct fwa_event { _private: [u8; 0] }
+#[repr(C)] pub struct fwa_comm { _private: [u8; 0] }
+
+pub const FWA_COMM_ID_BYTES: usize = 128;
 
 pub const FWA_OK: i32 = 0;
 pub const FWA_ERR_NO_DEVICE: i32 = 5;
+pub const FWA_ERR_UNSUPPORTED: i32 = 6;
 pub const FWA_FORWARD: i32 = 0;
 pub const FWA_INVERSE_SCALED: i32 = 1;
 pub const FWA_INVERSE_UNSCALED: i32 = 2;
@@ -23,10 +27,13 @@ extern "C" {
     pub fn fwa_last_error_string(ctx: *const fwa_ctx) -> *const c_char;
     pub fn fwa_status_string(status: i32) -> *const c_char;
     pub fn fwa_device_count(count: *mut i32) -> i32;
+    pub fn fwa_device_info(device_ordinal: i32, name: *mut c_char, name_cap: usize, compute_units: *mut i32, hbm_bytes: *mut u64, usable: *mut i32) -> i32;
     pub fn fwa_ctx_create(device_ordinal: i32, out: *mut *mut fwa_ctx) -> i32;
     pub fn fwa_ctx_destroy(ctx: *mut fwa_ctx) -> i32;
     pub fn fwa_ctx_synchronize(ctx: *mut fwa_ctx) -> i32;
     pub fn fwa_ctx_get_i64(ctx: *const fwa_ctx, key: *const c_char, value: *mut i64) -> i32;
+    pub fn fwa_ctx_set_i64(ctx: *mut fwa_ctx, key: *const c_char, value: i64) -> i32;
+    pub fn fwa_ctx_peer_access(ctx: *mut fwa_ctx, peer: *mut fwa_ctx, kind: *mut i32) -> i32;
     pub fn fwa_ctx_device_info(ctx: *const fwa_ctx, name: *mut c_char, name_cap: usize, compute_units: *mut i32, hbm_bytes: *mut u64) -> i32;
     pub fn fwa_stream_create(ctx: *mut fwa_ctx, out: *mut *mut fwa_stream) -> i32;
     pub fn fwa_stream_wrap(ctx: *mut fwa_ctx, hip_stream: *mut c_void, out: *mut *mut fwa_stream) -> i32;
@@ -50,6 +57,14 @@ extern "C" {
     pub fn fwa_describe_path(fft_len: u32, path: *mut i32, log2_factors: *mut u32) -> i32;
     pub fn fwa_plan_get_i64(plan: *const fwa_plan, key: *const c_char, value: *mut i64) -> i32;
     pub fn fwa_plan_set_i64(plan: *mut fwa_plan, key: *const c_char, value: i64) -> i32;
+    pub fn fwa_slab(batch: u64, rank: i32, world: i32, first: *mut u64, count: *mut u64) -> i32;
+    pub fn fwa_comm_unique_id(id: *mut u8) -> i32;
+    pub fn fwa_comm_create(ctx: *mut fwa_ctx, id: *const u8, world: i32, rank: i32, out: *mut *mut fwa_comm) -> i32;
+    pub fn fwa_comm_destroy(comm: *mut fwa_comm) -> i32;
+    pub fn fwa_comm_get_i64(comm: *const fwa_comm, key: *const c_char, value: *mut i64) -> i32;
+    pub fn fwa_comm_sendrecv(comm: *mut fwa_comm, send: *const fwa_buf, send_offset: u64, send_bytes: u64, send_to: i32, recv: *mut fwa_buf, recv_offset: u64, recv_bytes: u64, recv_from: i32, stream: *mut fwa_stream) -> i32;
+    pub fn fwa_comm_scatter(comm: *mut fwa_comm, root: i32, full_or_null: *const fwa_buf, slab: *mut fwa_buf, fft_len: u32, batch: u64, stream: *mut fwa_stream) -> i32;
+    pub fn fwa_comm_gather(comm: *mut fwa_comm, root: i32, slab: *const fwa_buf, full_or_null: *mut fwa_buf, fft_len: u32, batch: u64, stream: *mut fwa_stream) -> i32;
     pub fn fwa_event_create(ctx: *mut fwa_ctx, out: *mut *mut fwa_event) -> i32;
     pub fn fwa_event_record(ev: *mut fwa_event, stream: *mut fwa_stream) -> i32;
     pub fn fwa_event_synchronize(ev: *mut fwa_event) -> i32;

@@ -14,6 +14,7 @@ pub mod ffi;
 pub mod processor;
 pub use processor::*;
 pub mod wgpu_helper;
+pub mod sharded;
 /// Drop-in name for the objects the reference takes from the `wgpu` crate.
 pub use wgpu_helper as wgpu;
 
@@ -34,9 +35,15 @@ impl Complex {
     }
 }
 
-/// Reference `src/lib.rs:29-62` (`prepare_gpu`): a device and its queue, or `None` when no usable GPU exists.
+/// Reference `src/lib.rs:29-62` (`prepare_gpu`): lists the adapters (`:33-35`), asks for a high-performance one, opens a
+/// device and its queue; `None` when no usable GPU exists.
 pub fn prepare_gpu() -> Option<(wgpu::Device, wgpu::Queue)> {
-    wgpu::Device::open(0).map(|d| {
+    let instance = wgpu::Instance::default();
+    for adapter in instance.enumerate_adapters(wgpu::Backends::all()) {
+        eprintln!("{:?}", adapter.get_info()); // the reference `dbg!`s its adapter lists
+    }
+    let adapter = instance.enumerate_adapters(wgpu::Backends::all()).into_iter().next()?;
+    wgpu::Device::open(adapter.ordinal()).map(|d| {
         let q = d.queue();
         (d, q)
     })

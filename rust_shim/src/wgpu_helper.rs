@@ -3,6 +3,7 @@
 //! plans (`src/processor.rs`) and the three examples (`src/examples/basic.rs:6-30,50-64,68,73-122` and the same lines of
 //! `basic_inverse.rs`, `basic_inverse2.rs`) name, each a thin owner of one C-ABI handle of `include/fft_wgpu_amd.h`:
 //!
+//!   Instance::default() -> enumerate_adapters(Backends::VULKAN) -> Vec<Adapter> (one per GPU ordinal; adapter.get_info())
 //!   Instance::default() -> request_adapter(&RequestAdapterOptions { power_preference, .. }).await -> Option<Adapter>
 //!   adapter.features() / limits(); adapter.request_device(&DeviceDescriptor { .. }, None).await -> Result<(Device, Queue), _>
 //!   device.create_buffer(&BufferDescriptor { label, size, usage: BufferUsages::A | BufferUsages::B, mapped_at_creation })
@@ -70,21 +71,84 @@ pub struct DeviceDescriptor<'a> {
 #[derive(Debug)]
 pub struct RequestDeviceError(pub String);
 
+/// `wgpu::Backends`: accepted and ignored -- there is one backend here (HIP on gfx950).  The reference lists its adapters per
+/// backend (`src/lib.rs:33-35`: `VULKAN`, `GL`, `METAL`); to keep such a listing free of duplicates only the backends an
+/// MI355X host would really answer on (`VULKAN`, `PRIMARY`, `all()`) return the devices, the others an empty list.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub struct Backends(pub u32);
+impl Backends {
+    pub const VULKAN: Backends = Backends(1 << 0);
+    pub const GL: Backends = Backends(1 << 1);
+    pub const METAL: Backends = Backends(1 << 2);
+    pub const DX12: Backends = Backends(1 << 3);
+    pub const BROWSER_WEBGPU: Backends = Backends(1 << 4);
+    pub const PRIMARY: Backends = Backends(1 << 0 | 1 << 2 | 1 << 3 | 1 << 4);
+    pub const fn all() -> Self {
+        Backends(0x1f)
+    }
+}
+
+/// `wgpu::AdapterInfo` as far as it can be filled from `fwa_device_info`.
+#[derive(Clone, Debug)]
+pub struct AdapterInfo {
+    pub name: String,        // gcnArchName, e.g. "gfx950:sramecc+:xnack-"
+    pub device: u32,         // the HIP device ordinal
+    pub compute_units: i32,
+    pub hbm_bytes: u64,
+}
+
 /// `wgpu::Adapter`: a GPU ordinal that was found usable.
+#[derive(Debug)]
 pub struct Adapter {
     ordinal: i32,
 }
 
 impl Instance {
-    /// `None` when no gfx950 device is visible (`prepare_gpu` -> `None`, `src/lib.rs:43`).
-    pub fn request_adapter(&self, _options: &RequestAdapterOptions) -> Ready<Option<Adapter>> {
+    /// `instance.enumerate_adapters(Backends::VULKAN)` (`src/lib.rs:33-35`): one adapter per usable GPU ordinal, in ordinal
+    /// order -- what a multi-GPU caller iterates to open one `Device` per GPU (`sharded::ShardedBatch`).
+    pub fn enumerate_adapters(&self, backends: Backends) -> Vec<Adapter> {
+        let mut out = Vec::new();
+        if backends.0 & Backends::VULKAN.0 == 0 {
+            return out;
+        }
         let mut n: i32 = 0;
-        let st = unsafe { fwa_device_count(&mut n) };
-        ready(if st == FWA_OK && n > 0 { Some(Adapter { ordinal: 0 }) } else { None })
+        if unsafe { fwa_device_count(&mut n) } != FWA_OK {
+            return out;
+        }
+        for ordinal in 0..n {
+            let mut usable: i32 = 0;
+            let st = unsafe { fwa_device_info(ordinal, ptr::null_mut(), 0, ptr::null_mut(), ptr::null_mut(), &mut usable) };
+            if st == FWA_OK && usable != 0 {
+                out.push(Adapter { ordinal });
+            }
+        }
+        out
+    }
+
+    /// `None` when no gfx950 device is visible (`prepare_gpu` -> `None`, `src/lib.rs:43`); otherwise the first usable one
+    /// (every MI355X of a node is equally "high performance").
+    pub fn request_adapter(&self, _options: &RequestAdapterOptions) -> Ready<Option<Adapter>> {
+        ready(self.enumerate_adapters(Backends::all()).into_iter().next())
     }
 }
 
 impl Adapter {
+    /// `adapter.get_info()`
+    pub fn get_info(&self) -> AdapterInfo {
+        let mut name = [0 as std::os::raw::c_char; 256];
+        let (mut cus, mut mem, mut usable) = (0i32, 0u64, 0i32);
+        check(ptr::null(), unsafe { fwa_device_info(self.ordinal, name.as_mut_ptr(), name.len(), &mut cus, &mut mem, &mut usable) }, "fwa_device_info");
+        AdapterInfo {
+            name: unsafe { CStr::from_ptr(name.as_ptr()) }.to_string_lossy().into_owned(),
+            device: self.ordinal as u32,
+            compute_units: cus,
+            hbm_bytes: mem,
+        }
+    }
+    /// The HIP device ordinal behind this adapter.
+    pub fn ordinal(&self) -> i32 {
+        self.ordinal
+    }
     pub fn features(&self) -> Features {
         Features
     }

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     # and the ctypes table covers the header exactly
     assert sorted(_ffi._SIGNATURES) == names
-    assert L.fwa_abi_version() == 2
+    assert L.fwa_abi_version() == 3
 
 
 def test_laboratory_library_has_the_same_abi_and_the_product_has_no_laboratory_kernels():
@@ -110,6 +110,17 @@ def test_rust_shim_is_sound_and_covers_the_wgpu_surface_of_the_reference_example
                  ".unmap()", ".copy_buffer_to_buffer(", "queue.submit(Some(encoder.finish()))", "queue.write_buffer("):
         assert call in example, call
     assert "pub use wgpu_helper as wgpu;" in src["lib.rs"]
+    # the reference lists its adapters (src/lib.rs:33-35: instance.enumerate_adapters(Backends::VULKAN));
+    # the stand-in has the same call, one adapter per usable ordinal of fwa_device_count, and prepare_gpu goes through it
+    for item in ("pub fn enumerate_adapters(&self, backends: Backends) -> Vec<Adapter>", "pub struct Backends(pub u32);",
+                 "pub const VULKAN: Backends", "pub const GL: Backends", "pub const METAL: Backends", "pub fn get_info(&self) -> AdapterInfo",
+                 "fwa_device_info(ordinal,", "fwa_device_count(&mut n)"):
+        assert item in helper, item
+    assert "instance.enumerate_adapters(wgpu::Backends::all())" in src["lib.rs"] and "pub mod sharded;" in src["lib.rs"]
+    sharded = open(os.path.join(ROOT, "rust_shim", "src", "sharded.rs")).read()
+    for item in ("pub fn slab(batch: u64, rank: i32, world: i32) -> (u64, u64)", "fwa_slab(batch, rank, world,", "pub fn open_shards(",
+                 "instance.enumerate_adapters(wgpu::Backends::all())", "pub struct ShardedBatch<'a, P: ShardPlan<'a>>", "fwa_comm_scatter(", "fwa_comm_gather("):
+        assert item in sharded, item
 
 
 def test_no_device_is_an_error_not_a_fallback():

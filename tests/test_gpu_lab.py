@@ -128,3 +128,33 @@ def test_team_rejects_grids_that_cannot_form_a_team(gpu, oracle):
         plan.set("wgs", team)
     assert e.value.status == 1
     plan.set("wgs", 8 * team)
+
+
+@pytest.mark.parametrize("n,batch,group,streams,fail_at", [(1 << 20, 40, 4, 2, 7), (1 << 20, 40, 4, 2, 0), (1 << 18, 64, 8, 2, 5), (1 << 20, 12, 4, 1, 2)])
+def test_failed_launch_mid_exec_still_joins_the_chains(gpu, oracle, n, batch, group, streams, fail_at):
+    """when a launch fails in the middle of an exec (forced here with the laboratory knob
+    "inject_launch_failure": group `fail_at` is not launched, once), fwa_plan_exec returns FWA_ERR_LAUNCH -- and the groups
+    enqueued before the failure, which run on the context's chain streams, are still joined to the caller's stream: a copy of
+    the result buffer enqueued on that stream right after the failed call sees every one of them finished (bit-identical to
+    a clean run), the groups from the failed one on untouched.  The plan works again afterwards (the failure is one-shot)."""
+    fw, dev, queue = gpu
+    x = oracle.gen_input(n, batch, first_transform=21)
+    ref, _, _ = _run(fw, dev, queue, "Forward", x, n, group=group, streams=streams)
+    src = dev.create_buffer(x.nbytes)
+    snap = dev.create_buffer(x.nbytes)
+    enc = dev.create_command_encoder()
+    plan = fw.Forward(dev, queue, src, n)
+    for k, v in (("group", group), ("streams", streams), ("inject_launch_failure", fail_at)):
+        plan.set(k, v)
+    queue.write_buffer(src, 0, x, encoder=enc)
+    with pytest.raises(fw.FwaError) as e:
+        plan.proc(enc)
+    assert e.value.status == 4                                                   # FWA_ERR_LAUNCH
+    enc.copy_buffer_to_buffer(src, 0, snap, 0, x.nbytes)                         # ordered behind the chains only through the join
+    y = snap.map_read(stream=enc)
+    done = fail_at * group * n                                                   # samples of the groups enqueued before the failure
+    assert np.array_equal(y[:done].view(np.uint64), ref[:done].view(np.uint64))
+    assert np.array_equal(y[done:].view(np.uint64), x[done:].view(np.uint64))   # in place: never launched = still the input
+    queue.write_buffer(src, 0, x, encoder=enc)
+    z = plan.proc(enc).map_read(stream=enc)
+    assert np.array_equal(z.view(np.uint64), ref.view(np.uint64))

@@ -737,9 +737,11 @@ def test_cpp_host_pipeline_replays_reference_benchmark_loop(gpu, tmp_path):
     m = re.search(r"samples checked (\d+) max abs error ([0-9.e+-]+)", r.stdout)
     assert m and int(m.group(1)) == 200 * 512 * 2500 and float(m.group(2)) <= REF_ABS_TOL
     rate = float(re.search(r"pipeline only: [0-9.]+ iterations/s, ([0-9.]+) GB/s each way", r.stdout).group(1))
-    # 43.5 GB/s each way standalone (profiles/round3/host_pipeline_cpp.txt; the link carries 47 with both directions busy);
-    # as a child of this pytest process, which holds a context and streams of its own on the same GPU, about half of that
-    assert rate >= 12.0, r.stdout
+    link = float(re.search(r"link only \(both directions busy, no transform\): ([0-9.]+) GB/s each way", r.stdout).group(1))
+    # judged against the link rate the SAME child measures right after the pipeline (same
+    # transfer size, both directions busy, no transform) -- standalone 43.5 of 47-48 GB/s each way
+    # (profiles/round3/host_pipeline_cpp.txt); a child of this pytest process sees less of both, in the same proportion
+    assert rate >= 0.8 * link and link >= 10.0, r.stdout
 
 
 def test_plan_owned_result_buffer_outlives_temporary_plan(gpu, oracle):

@@ -29,6 +29,84 @@ def test_slabs_cover_batch_exactly():
         slab(8, 2, 2)
 
 
+def test_c_abi_and_cpp_slab_rule_for_world_1_to_8(tmp_path):
+    """VERDICT round 3, item 1: one slab rule everywhere.  fwa_slab (the C ABI; sharding.slab calls it), fft_wgpu::slab
+    (include/fft_wgpu.hpp, compiled here) and the divmod formula restated in this test agree for world 1..8, ragged and
+    empty batches, C4's 32768 and counts beyond 2^32."""
+    import ctypes
+    import subprocess
+    from fft_wgpu_amd import _ffi
+    from fft_wgpu_amd.sharding import slab
+    L = _ffi.lib()
+    batches = [0, 1, 2, 5, 7, 8, 9, 63, 4096, 32768, 32769, (1 << 33) + 5]
+
+    def formula(batch, r, world):
+        base, extra = divmod(batch, world)
+        first = r * base + min(r, extra)
+        return first, base + (1 if r < extra else 0)
+
+    src = tmp_path / "slabs.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "fft_wgpu.hpp"\n'
+                   'int main(int argc, char **argv) {\n'
+                   '  for (int i = 1; i < argc; ++i) for (int w = 1; w <= 8; ++w) for (int r = 0; r < w; ++r) {\n'
+                   '    fft_wgpu::Slab s = fft_wgpu::slab(std::strtoull(argv[i], nullptr, 10), r, w);\n'
+                   '    std::printf("%s %d %d %llu %llu\\n", argv[i], w, r, (unsigned long long)s.first, (unsigned long long)s.count); }\n'
+                   '  try { fft_wgpu::slab(8, 2, 2); } catch (const fft_wgpu::Error &e) { std::printf("rejected %d\\n", e.status); }\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "slabs"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)] + [str(b) for b in batches], env=env, capture_output=True, text=True, check=True).stdout.split("\n")
+    cpp = {}
+    for line in out:
+        f = line.split()
+        if len(f) == 5:
+            cpp[(int(f[0]), int(f[1]), int(f[2]))] = (int(f[3]), int(f[4]))
+    assert "rejected 1" in out                                   # FWA_ERR_INVALID_ARG, as sharding.slab's ValueError
+    for batch in batches:
+        for world in range(1, 9):
+            nxt = 0
+            for r in range(world):
+                first, count = ctypes.c_uint64(), ctypes.c_uint64()
+                assert L.fwa_slab(batch, r, world, ctypes.byref(first), ctypes.byref(count)) == 0
+                want = formula(batch, r, world)
+                assert (first.value, count.value) == want == cpp[(batch, world, r)]
+                assert slab(batch, r, world) == (want[0], want[0] + want[1])
+                assert first.value == nxt
+                nxt += count.value
+            assert nxt == batch
+    f, c = ctypes.c_uint64(), ctypes.c_uint64()
+    assert L.fwa_slab(8, 2, 2, ctypes.byref(f), ctypes.byref(c)) == 1 and L.fwa_slab(8, 0, 0, ctypes.byref(f), ctypes.byref(c)) == 1
+    assert L.fwa_slab(8, 0, 1, None, ctypes.byref(c)) == 1
+
+
+def test_multi_gpu_entry_points_reject_bad_handles_without_a_device():
+    """The multi-GPU part of the boundary fails with status codes, never a crash, when there is nothing to run on."""
+    import ctypes
+    from fft_wgpu_amd import _ffi
+    L = _ffi.lib()
+    out = ctypes.c_void_p()
+    k = ctypes.c_int32()
+    assert L.fwa_comm_create(None, None, 1, 0, ctypes.byref(out)) == 1 and not out.value
+    assert L.fwa_comm_scatter(None, 0, None, None, 1024, 4, None) == 1
+    assert L.fwa_comm_gather(None, 0, None, None, 1024, 4, None) == 1
+    assert L.fwa_comm_sendrecv(None, None, 0, 0, -1, None, 0, 0, -1, None) == 1
+    assert L.fwa_comm_unique_id(None) == 1
+    assert L.fwa_comm_destroy(None) == 0
+    assert L.fwa_ctx_peer_access(None, None, ctypes.byref(k)) == 1
+    assert L.fwa_ctx_set_i64(None, b"chain_check", 0) == 1
+    assert L.fwa_buf_copy(None, 0, None, 0, 0, None) == 1
+    if torch.cuda.device_count() == 0:
+        import fft_wgpu_amd as fw
+        assert fw.enumerate_adapters() == [] and fw.device_count() == 0
+        ok = ctypes.c_int32(7)
+        assert L.fwa_device_info(0, None, 0, None, None, ctypes.byref(ok)) == 5 and ok.value == 0   # FWA_ERR_NO_DEVICE
+        with pytest.raises(fw.FwaError) as e:
+            fw.ShardedBatch(fw.Forward, 1024, 8)
+        assert e.value.status == 5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
