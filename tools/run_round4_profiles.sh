@@ -1,0 +1,33 @@
+#!/bin/bash
+# tools/run_round4_profiles.sh -- the measurement set behind profiles/round4/a_* and b_* (run on the GPU box through gpurun):
+# bench line, rocprofv3 kernel stats (default and single-chain), PMC fetch / write passes, size sweeps at both footprints
+# (n <= 2^24: the contract's range), the four plan kinds, the batch-1 shapes, host link / pipelines.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/round4
+mkdir -p $O
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/a_bench_default.json 2> $O/bench_default.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --spread 0 > $O/prof_default.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_streams1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --spread 0 --streams 1 > $O/prof_streams1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --spread 0 > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --spread 0 > $O/pmc_write.log 2>&1
+python3 tools/pmc_summary.py $O/pmc_fetch > $O/a_pmc_fetch_summary.txt
+python3 tools/pmc_summary.py $O/pmc_write > $O/a_pmc_write_summary.txt
+python3 tools/trace_summary.py $O/prof_default > $O/a_trace_default_summary.txt
+python3 tools/trace_summary.py $O/prof_streams1 > $O/a_trace_streams1_summary.txt
+cp "$(find $O/prof_default -name '*kernel_stats.csv' | head -1)" $O/a_kernel_stats_default.csv
+cp "$(find $O/prof_streams1 -name '*kernel_stats.csv' | head -1)" $O/a_kernel_stats_streams1_isolated.csv
+rm -rf $O/prof_default $O/prof_streams1 $O/pmc_fetch $O/pmc_write
+echo "profiles done"
+timeout -k 10 400 python3 tools/size_bench.py --lg-max 24 > $O/b_size_sweep_2GiB.jsonl 2>&1
+timeout -k 10 400 python3 tools/size_bench.py --lg-min 9 --lg-max 24 --total-lg 32 --no-latency-shapes > $O/b_size_sweep_32GiB.jsonl 2>&1
+echo "sweeps done"
+timeout -k 10 200 python3 tools/latency_shapes.py --label head > $O/latency_shapes.jsonl 2>&1
+timeout -k 10 200 python3 tools/kinds_bench.py > $O/kinds_bench.jsonl 2>&1
+timeout -k 10 200 python3 tools/reference_loop.py --iters 1000 > $O/d_reference_loop_pcie_inclusive.jsonl 2>&1
+timeout -k 10 100 python3 tools/link_probe.py > $O/host_link.jsonl 2>&1
+g++ -O2 -std=c++17 -Iinclude tools/example_basic_pipeline.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -o /tmp/example_basic_pipeline
+LD_LIBRARY_PATH=fft_wgpu_amd timeout -k 10 200 /tmp/example_basic_pipeline 300 3 > $O/host_pipeline_cpp.txt 2>&1
+g++ -O2 -std=c++17 -Iinclude tools/example_sharded.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -o /tmp/example_sharded
+for a in "10 37 0" "20 9 2" "16 9 3"; do LD_LIBRARY_PATH=fft_wgpu_amd timeout -k 10 100 /tmp/example_sharded $a >> $O/sharded_cpp.txt 2>&1; done
+echo done
