@@ -432,7 +432,7 @@ def test_config_c5_n16m_batch1(gpu, oracle):
     n = 1 << 24
     x = oracle.gen_input(n, 1)
     y, which, plan = _run(fw, dev, queue, "Forward", x, n)
-    assert which == 0 and plan.get("path") == 7  # tiled: 256 x 256 x 256, three k_tile16 passes
+    assert which == 0 and plan.get("path") == 7 and plan.get("factors") == (9 | (7 << 8) | (8 << 16))  # tiled: 512 x 128 x 256 -- k_colsw (512 x 32 column tiles), then two k_tile passes
     mx, l2 = _check(oracle, y, oracle.dft_f64(x, n, -1), n)
     print("C5 max_rel %.3g rel_l2 %.3g" % (mx, l2))
 
