@@ -1,29 +1,33 @@
-// kernels_chunk.hip -- n = 4 .. 256: whole transforms inside a contiguous 32-KiB chunk per workgroup (gfx950 only).
+// kernels_chunk.hip -- n = 2 .. 256: whole transforms inside a contiguous 64-KiB chunk per workgroup (gfx950 only).
 //
 // Below n = 512 a transform is shorter than what a wavefront moves with one instruction, so a kernel whose lanes
-// address "their" points directly (k_tiny16, k_small16) issues loads whose lanes are 16 .. 128 bytes apart: every
-// instruction touches up to 64 cache lines and the same line is touched by up to 16 instructions (0.52-0.67 of the
-// roofline).  Here global memory is only ever addressed linearly: thread `tid` of the 256 loads samples
-// u*256 + tid (u < 16) of the chunk -- 512 contiguous bytes per wavefront instruction, all 16 loads in flight before
-// the first use -- parks them in LDS (one pad element per 16: conflict-free on both sides), and the transform
-// arithmetic reads its operands from there: 16 points per thread, radix 16 [x 2, 4, 8, 16] with one exchange, as in
-// k_small16 (same recurrence, fft.wgsl:27-62 generalised to radix R; twiddle table of processor.rs:43-49).  The
-// results go back through LDS to linear stores.  The buffer descriptor ends with the data, so a ragged last chunk
-// needs no bounds code (loads return 0, stores are dropped); a chunk holds whole transforms only (n divides 4096).
-// In place allowed: a workgroup reads its chunk completely before it writes any of it.
+// address "their" points directly (k_tiny16, k_small16: laboratory build) issues loads whose lanes are 16 .. 128 bytes apart:
+// every instruction touches up to 64 cache lines and the same line is touched by up to 16 instructions (0.52-0.67 of the
+// roofline).  Here global memory is only ever addressed linearly, in the launch shape that streams fastest on this part
+// (tools/stream_probe.hip, profiles/round4/probe_stream_shapes.txt: 6.3 TB/s against 5.5-5.9 for every shape whose instructions
+// hop through the chunk -- round 2's 32-KiB chunks included): one 256-thread workgroup per 64-KiB-aligned chunk, every WAVE
+// walks its own 16 KiB front to back with 32 loads of 512 contiguous bytes, all in flight before the first use.  The
+// arithmetic runs on one HALF of the chunk at a time (the first 8 KiB of every wave's range, then the second: 4096 samples
+// = whole transforms, n divides 1024): the half is parked in LDS (one pad element per 16: conflict-free on both sides) and
+// transformed there -- 16 points per thread, radix 16 [x 2, 4, 8, 16] with one exchange, the recurrence of fft.wgsl:27-62
+// generalised to radix R, twiddle table of processor.rs:43-49 -- and read back into the registers it came from; 34 KiB of LDS,
+// four workgroups per CU.  32 linear stores follow.  The buffer descriptor ends with the data, so a ragged last chunk needs
+// no bounds code (loads return 0, stores are dropped).  In place allowed: a workgroup reads its chunk completely before it
+// writes any of it.
 #include "device_common.h"
 
 namespace fwa {
 
-// T = 512 / 1024 threads per workgroup and default / sc1 policies on either side measured within noise of or slower than
-// 256 threads with nt on both sides (profiles/round2/probe_chunk_variants.txt).
-template <int LGN, int DIR, int T = 256, int AIN = AUX_NT, int AOUT = AUX_NT>
-__global__ __launch_bounds__(T) void k_chunk(const v2f *__restrict__ src, v2f *__restrict__ dst,
-                                               const v2f *__restrict__ tw, uint64_t n_samples, float scale)
+template <int LGN, int DIR, int AIN = AUX_NT, int AOUT = AUX_NT>
+__global__ __launch_bounds__(256, (LGN >= 6 ? 3 : 4)) void k_chunk(const v2f *__restrict__ src, v2f *__restrict__ dst,
+                                                  const v2f *__restrict__ tw, uint64_t n_samples, float scale)
 {
     constexpr int N = 1 << LGN;
-    constexpr uint32_t CH = 16 * T;  // samples per workgroup
-    __shared__ v2f lds_all[CH + CH / 16];
+    constexpr int T = 256;
+    constexpr uint32_t CH = 32 * T;   // samples per workgroup (64 KiB)
+    constexpr uint32_t HALF = 16 * T;  // samples transformed at a time
+    constexpr bool EARLY = LGN >= 6;   // store a half as soon as it is done (register pressure: see below)
+    __shared__ v2f lds_all[HALF + HALF / 16];
     const uint32_t tid = threadIdx.x;
     const uint64_t e0 = (uint64_t)blockIdx.x * CH;
     const uint64_t left = n_samples - e0;
@@ -31,10 +35,20 @@ __global__ __launch_bounds__(T) void k_chunk(const v2f *__restrict__ src, v2f *_
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + e0), 0, valid, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + e0, 0, valid, 0x00020000);
     auto pad = [](uint32_t p) { return p + (p >> 4); };
+    // wave w walks samples [2048 w, 2048 w + 2048) of the chunk: access i covers samples 2048 w + 64 i + lane
+    const uint32_t wv = tid >> 6, lane = tid & 63;
+    const uint32_t voff = (wv * 2048 + lane) * 8;
+    // ... and access i of half h = i / 16 sits at position 1024 w + 64 (i % 16) + lane of the half's LDS space: the four
+    // 1024-sample blocks of a half are whole transforms, back to back
+    const uint32_t park = wv * 1024 + lane;
 
+    v2f y[32];
+    static_for<0, 32>([&](auto i_) { constexpr int i = decltype(i_)::value; y[i] = buf_load<AIN>(rin, voff, i * 512); });
+  static_for<0, 2>([&](auto h_) {
+    constexpr int h = decltype(h_)::value;
     v2f x[16], v[16];
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = buf_load<AIN>(rin, tid * 8, u * T * 8); });
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_all[pad(u * T + tid)] = x[u]; });
+    if constexpr (h == 1) __syncthreads();  // the first half has been read back
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; lds_all[pad(park + 64 * u)] = y[16 * h + u]; });
     __syncthreads();
 
     if constexpr (LGN <= 4) {
@@ -88,15 +102,20 @@ __global__ __launch_bounds__(T) void k_chunk(const v2f *__restrict__ src, v2f *_
         }
     }
     __syncthreads();
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = lds_all[pad(u * T + tid)]; });
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; buf_store<AOUT>(x[u], rout, tid * 8, u * T * 8); });
+    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; y[16 * h + u] = lds_all[pad(park + 64 * u)]; });
+    // from n = 64 on the two-stage arithmetic needs the registers of the finished half: its 16 stores go out at once
+    if constexpr (EARLY)
+        static_for<0, 16>([&](auto u_) { constexpr int i = 16 * h + decltype(u_)::value; buf_store<AOUT>(y[i], rout, voff, i * 512); });
+  });
+    if constexpr (!EARLY)
+        static_for<0, 32>([&](auto i_) { constexpr int i = decltype(i_)::value; buf_store<AOUT>(y[i], rout, voff, i * 512); });
 }
 
 template <int DIR>
 static hipError_t launch_chunk_dir(const v2f *src, v2f *dst, const v2f *tw, uint32_t lg_n, uint64_t n_samples, float scale,
                                    hipStream_t st)
 {
-    const uint64_t blocks = (n_samples + 4095) / 4096;
+    const uint64_t blocks = (n_samples + 8191) / 8192;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)blocks), b(256);
     switch (lg_n) {

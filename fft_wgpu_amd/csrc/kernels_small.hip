@@ -57,22 +57,24 @@ hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uin
 // ---------------------------------------------------------------------------
 // elementwise: normalize (normalize.wgsl:9-12), synthetic fill, calibration copy
 // ---------------------------------------------------------------------------
-// normalize: the shape of the one-launch FFT kernels (k_chunk): one workgroup per contiguous 32-KiB chunk, linear `nt`
-// buffer accesses, all 16 loads of a thread in flight before the first store; the descriptor ends with the data, so
-// a ragged last chunk needs no bounds code.  (A grid-stride float4 loop with default policy: 0.55-0.63 of the
-// roofline; this shape: the streaming rate of the FFT kernels.)
+// normalize: a streaming pass in the launch shape that measured fastest on this part (tools/stream_probe.hip,
+// profiles/round4/probe_stream_shapes.txt): one 256-thread workgroup per contiguous, 64-KiB-aligned chunk, every WAVE walks its
+// own 16 KiB front to back -- 32 `nt` loads of 512 contiguous bytes per wave, all in flight before the first store.  That is the
+// addressing of k_small32 (6.2-6.4 TB/s); chunks of 32 KiB, or instructions that cover 2 KiB of the workgroup's chunk and hop
+// on (round 2's shape), stay at 5.5-5.9 TB/s.  The descriptor ends with the data, so a ragged last chunk needs no bounds code.
 __global__ __launch_bounds__(256) void k_scale(const v2f *__restrict__ a, v2f *__restrict__ b, uint64_t n_samples,
                                                float scale)
 {
-    constexpr uint32_t CH = 4096;  // samples per workgroup
+    constexpr uint32_t CH = 8192;  // samples per workgroup
     const uint64_t e0 = (uint64_t)blockIdx.x * CH;
     const uint64_t left = n_samples - e0;
     const uint32_t valid = left < CH ? (uint32_t)left * 8u : CH * 8u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(a + e0), 0, valid, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(b + e0, 0, valid, 0x00020000);
-    v2f x[16];
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = buf_load<AUX_NT>(rin, threadIdx.x * 8, u * 2048); });
-    static_for<0, 16>([&](auto u_) { constexpr int u = decltype(u_)::value; buf_store<AUX_NT>(x[u] * scale, rout, threadIdx.x * 8, u * 2048); });
+    const uint32_t voff = (threadIdx.x >> 6) * 16384 + (threadIdx.x & 63) * 8;
+    v2f x[32];
+    static_for<0, 32>([&](auto u_) { constexpr int u = decltype(u_)::value; x[u] = buf_load<AUX_NT>(rin, voff, u * 512); });
+    static_for<0, 32>([&](auto u_) { constexpr int u = decltype(u_)::value; buf_store<AUX_NT>(x[u] * scale, rout, voff, u * 512); });
 }
 
 static uint32_t stream_grid(uint64_t work_items)
@@ -87,7 +89,7 @@ static uint32_t stream_grid(uint64_t work_items)
 hipError_t launch_scale(const v2f *a, v2f *b, uint64_t n_samples, float scale, hipStream_t st)
 {
     if (n_samples == 0) return hipSuccess;
-    const uint64_t blocks = (n_samples + 4095) / 4096;
+    const uint64_t blocks = (n_samples + 8191) / 8192;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_scale, dim3((uint32_t)blocks), dim3(256), 0, st, a, b, n_samples, scale);
     return hipGetLastError();
@@ -122,21 +124,20 @@ hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st)
     return hipGetLastError();
 }
 
-// Calibration copy, shaped like the one-launch FFT kernels: one workgroup per contiguous 32-KiB chunk, every thread
-// issues its 16 non-temporal 8-byte loads (one complex sample each, as every FFT kernel does) before the first store.
-// tools/stream_probe.hip (profiles/round4/probe_stream_shapes.txt) compares lanes of 8 / 16 bytes x 8 / 16 / 32 accesses
-// per thread, in and out of place: 5.5-5.9 TB/s all of them, this shape on top; a grid-stride float4 loop with default
-// policy reaches 4.7-5.0 (profiles/round2/probe_copy_shapes.txt).
+// Calibration copy in the same shape as k_scale above: one workgroup per 64-KiB chunk, each wave walks 16 KiB with 32 `nt`
+// 8-byte-lane loads in flight before the first store (6.3-6.4 TB/s; a grid-stride float4 loop with default policy: 4.7-5.0,
+// chunk shapes whose instructions hop through the chunk: 5.5-5.9 -- profiles/round4/probe_stream_shapes.txt).
 __global__ __launch_bounds__(256) void k_copy(const char *__restrict__ a, char *__restrict__ b, uint64_t n_chunks)
 {
-    constexpr uint32_t CHUNK = 32768, U = 16;
+    constexpr uint32_t CHUNK = 65536, U = 32;
     const uint64_t c = blockIdx.x;
     if (c >= n_chunks) return;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * CHUNK, 0, CHUNK, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * CHUNK, 0, CHUNK, 0x00020000);
+    const uint32_t voff = (threadIdx.x >> 6) * 16384 + (threadIdx.x & 63) * 8;
     v2u x[U];
-    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = __builtin_amdgcn_raw_buffer_load_b64(ra, threadIdx.x * 8, i * 2048, AUX_NT); });
-    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, threadIdx.x * 8, i * 2048, AUX_NT); });
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = __builtin_amdgcn_raw_buffer_load_b64(ra, voff, i * 512, AUX_NT); });
+    static_for<0, U>([&](auto i_) { constexpr int i = decltype(i_)::value; __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, voff, i * 512, AUX_NT); });
 }
 
 __global__ __launch_bounds__(256) void k_copy_tail(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t first, uint64_t n_vec)
@@ -147,13 +148,13 @@ __global__ __launch_bounds__(256) void k_copy_tail(const v4f *__restrict__ a, v4
 
 hipError_t launch_copy(const void *src, void *dst, uint64_t bytes, hipStream_t st)
 {
-    const uint64_t n_chunks = bytes / 32768, n_vec = bytes / 16;
+    const uint64_t n_chunks = bytes / 65536, n_vec = bytes / 16;
     if (n_vec == 0) return hipSuccess;
     if (n_chunks > 0x7fffffffull) return hipErrorInvalidValue;
     if (n_chunks)
         hipLaunchKernelGGL(k_copy, dim3((uint32_t)n_chunks), dim3(256), 0, st, static_cast<const char *>(src),
                            static_cast<char *>(dst), n_chunks);
-    const uint64_t done = n_chunks * 2048;  // 16-byte vectors copied by the chunk kernel
+    const uint64_t done = n_chunks * 4096;  // 16-byte vectors copied by the chunk kernel
     if (n_vec > done)
         hipLaunchKernelGGL(k_copy_tail, dim3((uint32_t)((n_vec - done + 255) / 256)), dim3(256), 0, st,
                            static_cast<const v4f *>(src), static_cast<v4f *>(dst), done, n_vec);
