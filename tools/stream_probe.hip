@@ -67,6 +67,22 @@ __global__ __launch_bounds__(THREADS, OCC) void k_sweep8(const char *a, char *b)
 #pragma unroll
     for (int i = 0; i < U; ++i) __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, voff, i * 512, 2);
 }
+// mixed: which side needs the walk?  LD_SWEEP / ST_SWEEP: that side walks 16 KiB per wave (512-byte steps), the other side hops
+// through the 64-KiB chunk (every instruction of the workgroup covers 2 KiB); the values cross over through LDS-free register
+// renaming only when both sides agree, so here the copy permutes data inside the chunk (same bytes moved).
+template <bool LD_SWEEP, bool ST_SWEEP>
+__global__ __launch_bounds__(256, 2) void k_mixed(const char *a, char *b)
+{
+    const uint64_t c = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * 65536, 0, 65536, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * 65536, 0, 65536, 0x00020000);
+    const uint32_t sweep_off = (threadIdx.x >> 6) * 16384 + (threadIdx.x & 63) * 8, hop_off = threadIdx.x * 8;
+    v2u x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b64(ra, LD_SWEEP ? sweep_off : hop_off, i * (LD_SWEEP ? 512 : 2048), 2);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, ST_SWEEP ? sweep_off : hop_off, i * (ST_SWEEP ? 512 : 2048), 2);
+}
 // the same with 16-byte lanes: 1 KiB per wave instruction, U accesses -> each wave walks U KiB
 template <int U, int THREADS, int OCC>
 __global__ __launch_bounds__(THREADS, OCC) void k_sweep16(const char *a, char *b)
@@ -97,7 +113,9 @@ int main(int argc, char **argv)
 #define S16(U, T, O) {"sweep16 per wave, x " #U ", " #T " threads, occ " #O, k_sweep16<U, T, O>, 1024u * U * (T / 64), T}
               S16(8, 256, 2), S16(16, 256, 2), S16(32, 256, 1), S16(16, 128, 2), S16(16, 512, 1), S16(16, 64, 4), S16(24, 256, 1),
 #define S8(U, T, O) {"sweep8 per wave, x " #U ", " #T " threads, occ " #O, k_sweep8<U, T, O>, 512u * U * (T / 64), T}
-              S8(16, 512, 1), S8(16, 512, 2), S8(16, 1024, 1), S8(32, 128, 4), S8(32, 512, 1), S8(8, 1024, 1)};
+              S8(16, 512, 1), S8(16, 512, 2), S8(16, 1024, 1), S8(32, 128, 4), S8(32, 512, 1), S8(8, 1024, 1),
+              {"loads walk, stores hop", k_mixed<true, false>, 65536u}, {"loads hop, stores walk", k_mixed<false, true>, 65536u},
+              {"both hop (64 KiB chunk)", k_mixed<false, false>, 65536u}, {"both walk", k_mixed<true, true>, 65536u}};
     printf("%-34s %12s %12s   (GB/s read+write, %llu MiB each way)\n", "variant", "in place", "out of place", (unsigned long long)(bytes >> 20));
     for (auto &v : vs) {
         float best[2] = {1e30f, 1e30f};
