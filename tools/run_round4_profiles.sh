@@ -24,7 +24,8 @@ timeout -k 10 400 python3 tools/size_bench.py --lg-min 9 --lg-max 24 --total-lg 
 echo "sweeps done"
 timeout -k 10 200 python3 tools/latency_shapes.py --label head > $O/latency_shapes.jsonl 2>&1
 timeout -k 10 200 python3 tools/kinds_bench.py > $O/kinds_bench.jsonl 2>&1
-timeout -k 10 200 python3 tools/reference_loop.py --iters 1000 > $O/d_reference_loop_inside_profile_job.jsonl 2>&1
+sleep 3   # a process started right after one that freed tens of GiB runs its host copies serialised for ~0.5 s: profiles/round4/probe_pipe_slow_after_large_free.txt
+timeout -k 10 200 python3 tools/reference_loop.py --iters 1000 > $O/d_reference_loop_pcie_inclusive.jsonl 2>&1
 timeout -k 10 100 python3 tools/link_probe.py > $O/host_link.jsonl 2>&1
 g++ -O2 -std=c++17 -Iinclude tools/example_basic_pipeline.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -o /tmp/example_basic_pipeline
 LD_LIBRARY_PATH=fft_wgpu_amd timeout -k 10 200 /tmp/example_basic_pipeline 300 3 > $O/host_pipeline_cpp.txt 2>&1
