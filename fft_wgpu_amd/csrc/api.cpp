@@ -88,15 +88,17 @@ struct fwa_ctx {
     std::vector<int> peers_enabled;         // device ordinals this context's device has peer access to (enabled once)
 };
 struct fwa_stream {
-    fwa_ctx *ctx = nullptr;
+    fwa_ctx *ctx = nullptr;   // nullptr once the context has been destroyed (the handle can still be destroyed)
     hipStream_t s = nullptr;
     bool owned = false;
+    int device = -1;
 };
 struct fwa_buf {
     fwa_ctx *ctx = nullptr;
     void *p = nullptr;
     uint64_t bytes = 0;
     bool owned = false;
+    int device = -1;          // for fwa_buf_free after the context is gone
 };
 struct fwa_event {
     fwa_ctx *ctx = nullptr;
@@ -835,6 +837,8 @@ int32_t fwa_ctx_destroy(fwa_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->free_rings) (void)hipFree(kv.second);
     for (auto s : ctx->chains) (void)hipStreamDestroy(s);
+    // stream handles that outlive their context (a garbage-collected host language frees in any order) stay destroyable
+    for (fwa_stream *st : ctx->live_streams) st->ctx = nullptr;
     ctx->tables.clear();
     delete ctx;
     return FWA_OK;
@@ -919,7 +923,7 @@ int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
     if (rc) return rc;
     fwa_stream *st = new (std::nothrow) fwa_stream;
     if (!st) { (void)hipStreamDestroy(s); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-    st->ctx = ctx; st->s = s; st->owned = true;
+    st->ctx = ctx; st->s = s; st->owned = true; st->device = ctx->device;
     ctx->user_streams.push_back(s);
     ctx->live_streams.push_back(st);
     *out = st;
@@ -931,7 +935,7 @@ int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out)
     if (!ctx || !out) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/out is NULL");
     fwa_stream *st = new (std::nothrow) fwa_stream;
     if (!st) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
-    st->ctx = ctx; st->s = reinterpret_cast<hipStream_t>(hip_stream); st->owned = false;
+    st->ctx = ctx; st->s = reinterpret_cast<hipStream_t>(hip_stream); st->owned = false; st->device = ctx->device;
     ctx->live_streams.push_back(st);
     *out = st;
     return FWA_OK;
@@ -940,6 +944,7 @@ int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out)
 int32_t fwa_stream_synchronize(fwa_stream *stream)
 {
     if (!stream) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    if (!stream->ctx) return fail(nullptr, FWA_ERR_INVALID_ARG, "the stream's context has been destroyed");
     USE_DEVICE(stream->ctx);
     HIP_TRY(stream->ctx, hipStreamSynchronize(stream->s));
     return FWA_OK;
@@ -948,15 +953,14 @@ int32_t fwa_stream_synchronize(fwa_stream *stream)
 int32_t fwa_stream_destroy(fwa_stream *stream)
 {
     if (!stream) return FWA_OK;
-    {
+    if (stream->ctx) {
         auto &ls = stream->ctx->live_streams;
         ls.erase(std::remove(ls.begin(), ls.end(), stream), ls.end());
+        auto &us = stream->ctx->user_streams;
+        us.erase(std::remove(us.begin(), us.end(), stream->s), us.end());
     }
     if (stream->owned) {
-        (void)hipSetDevice(stream->ctx->device);
-        auto &us = stream->ctx->user_streams;
-        for (size_t i = 0; i < us.size(); ++i)
-            if (us[i] == stream->s) { us.erase(us.begin() + (std::ptrdiff_t)i); break; }
+        (void)hipSetDevice(stream->device);
         (void)hipStreamDestroy(stream->s);
     }
     delete stream;
@@ -976,7 +980,7 @@ int32_t fwa_buf_alloc(fwa_ctx *ctx, uint64_t bytes, fwa_buf **out)
     }
     fwa_buf *b = new (std::nothrow) fwa_buf;
     if (!b) { (void)hipFree(p); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-    b->ctx = ctx; b->p = p; b->bytes = bytes; b->owned = true;
+    b->ctx = ctx; b->p = p; b->bytes = bytes; b->owned = true; b->device = ctx->device;
     *out = b;
     return FWA_OK;
 }
@@ -988,7 +992,7 @@ int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **o
         return fail(ctx, FWA_ERR_INVALID_ARG, "device pointer must be 16-byte aligned");
     fwa_buf *b = new (std::nothrow) fwa_buf;
     if (!b) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
-    b->ctx = ctx; b->p = device_ptr; b->bytes = bytes; b->owned = false;
+    b->ctx = ctx; b->p = device_ptr; b->bytes = bytes; b->owned = false; b->device = ctx->device;
     *out = b;
     return FWA_OK;
 }
@@ -996,7 +1000,7 @@ int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **o
 int32_t fwa_buf_free(fwa_buf *buf)
 {
     if (!buf) return FWA_OK;
-    if (buf->owned && buf->p) { (void)hipSetDevice(buf->ctx->device); (void)hipFree(buf->p); }
+    if (buf->owned && buf->p) { (void)hipSetDevice(buf->device); (void)hipFree(buf->p); }
     delete buf;
     return FWA_OK;
 }
@@ -1120,7 +1124,7 @@ int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offs
 
 int32_t fwa_stream_wait_stream(fwa_stream *stream, fwa_stream *other)
 {
-    if (!stream || !other) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL");
+    if (!stream || !other || !stream->ctx) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL or its context has been destroyed");
     USE_DEVICE(stream->ctx);
     hipEvent_t ev;
     HIP_TRY(stream->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -31,6 +31,9 @@
  * of the context captures a graph; fwa_ctx_set_i64(ctx, "chain_check", 0)
  * turns the check off.
  *
+ * Lifetimes: plans and communicators go before their context, buffers before the plans that use them.  Buffer and
+ * stream HANDLES may be destroyed after their context (hosts with garbage collection free in any order); using one is an error.
+ *
  * Errors: every function returns an fwa_status (0 = ok).  Nothing aborts or
  * throws across the ABI.  fwa_last_error_string() gives detail.
  */

@@ -223,3 +223,23 @@ def test_stream_overlap_check_is_refused_during_capture_and_can_be_turned_off(gp
         enc.destroy()
     assert d.get("live_streams") == 1
     assert hip.hipStreamDestroy(stream) == 0
+
+
+def test_stream_and_buffer_handles_may_outlive_their_context(gpu, oracle):
+    """A host with garbage collection frees in any order: destroying a stream or a buffer handle after its context is legal
+    (using the stream is an error, not a crash), and the next launch on another context is unaffected."""
+    fw, dev, queue = gpu
+    d = fw.Device(0)
+    enc = d.create_command_encoder()
+    buf = d.create_buffer(1 << 20)
+    L = d._L
+    eh, bh = enc._h, buf._h
+    enc._h = buf._h = None                       # keep the Python wrappers from freeing them first
+    d._default.destroy()
+    d.destroy()
+    assert L.fwa_stream_synchronize(eh) == 1
+    assert L.fwa_stream_destroy(eh) == 0 and L.fwa_buf_free(bh) == 0
+    x = oracle.gen_input(1024, 3)
+    y, _, _ = _run(fw, dev, queue, "Forward", x, 1024)
+    mx, _ = oracle.compare(y[:1024], oracle.dft_f64(x[:1024], 1024, -1))
+    assert mx <= 1e-5
