@@ -180,8 +180,8 @@ def main():
 
     # calibration on the same stream, same run (rank 0): what a single streaming pass sustains on this box --
     #  * in place (every line read, then written back: the traffic of the one-launch FFT kernels; fwa_calib_copy with
-    #    dst == src runs the normalize kernel's shape: 32-KiB chunk per workgroup, 16 nt loads in flight per thread),
-    #  * out of place (8 GiB -> another 8 GiB: one workgroup per 64-KiB chunk, nt).
+    #    dst == src runs the normalize kernel: one workgroup per 64-KiB chunk, every wave walks 16 KiB, 32 nt loads in flight),
+    #  * out of place (8 GiB -> another 8 GiB, the same launch shape).
     copy_gbps = stream_gbps = None
     spread = single_pass = None
     if rank == 0:
@@ -293,7 +293,7 @@ def main():
                          "algorithmic_bytes_per_exec": ALGO_BYTES_PER_SAMPLE * n * batch,
                          # what ONE streaming pass over the data sustains in this run: in place (the one-launch FFT kernels'
                          # traffic) and out of place; a two-pass transform moves 32 B/sample at about this rate
-                         "copy_ceiling_GBps_same_run": stream_gbps, "copy_ceiling_kind": "in-place read + write-back of 16 GiB, one workgroup per 32-KiB chunk, 16 nt 8-byte loads in flight per thread",
+                         "copy_ceiling_GBps_same_run": stream_gbps, "copy_ceiling_kind": "in-place read + write-back of 16 GiB; one workgroup per 64-KiB chunk, every wave walks 16 KiB, 32 nt 8-byte loads in flight per thread (profiles/round4/probe_stream_shapes.txt)",
                          "copy_out_of_place_GBps_same_run": copy_gbps,
                          "single_pass_reference_same_run": single_pass,
                          "exec_spread_hip_events": spread},

@@ -1700,7 +1700,7 @@ int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_str
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
     USE_DEVICE(dst->ctx);
     // dst == src: an in-place streaming pass (every line read, then written back) -- the normalize kernel with scale 1:
-    // 32-KiB chunk per workgroup, 16 nt loads in flight per thread, the traffic pattern of the one-launch FFT kernels
+    // 64-KiB chunk per workgroup, every wave walks 16 KiB with 32 nt loads in flight: the fastest streaming shape on this part
     hipError_t e = (dst->p == src->p) ? fwa::launch_scale(static_cast<const v2f *>(src->p), static_cast<v2f *>(dst->p), bytes / 8, 1.0f, raw(stream))
                                       : fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
     if (e != hipSuccess) return fail_hip(dst->ctx, e, "copy launch", FWA_ERR_LAUNCH);

@@ -6,7 +6,7 @@ namespace fwa {
 
 hipError_t launch_r2_stage(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint32_t stage,
                            uint64_t batch, float scale, hipStream_t st);
-// 4 <= n <= 256: contiguous 32-KiB chunks per workgroup, linear global access, operands staged in LDS
+// 2 <= n <= 256: contiguous 64-KiB chunks per workgroup, every wave walks 16 KiB linearly, operands staged in LDS half by half
 // (kernels_chunk.hip: k_chunk); in place allowed
 hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                         hipStream_t st);
