@@ -5,6 +5,7 @@
 // Errors: the reference unwraps / panics (examples/basic.rs:14,30,106); this mirror throws
 // fft_wgpu::Error carrying the fwa_status and fwa_last_error_string().
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -375,6 +376,54 @@ private:
     std::vector<std::unique_ptr<Buffer>> buf_, second_;
     std::vector<std::unique_ptr<PlanT>> plan_;
     std::vector<Buffer *> result_;
+};
+
+// One rank of a slab communicator over RCCL (fwa_comm_*), for hosts that run ONE PROCESS PER GPU and do not hold each other's
+// pointers (the twin of fft_wgpu_amd.sharding.Comm and rust_shim's sharded::Comm).  Rank 0 calls Comm::unique_id() and hands the
+// bytes to the other ranks (file, socket, launcher environment); every rank then constructs its Comm (collective).  scatter /
+// gather move whole-transform slabs by the slab rule, stream-ordered on `enc`; the transform itself never communicates.
+class Comm {
+public:
+    using Id = std::array<uint8_t, FWA_COMM_ID_BYTES>;
+    static Id unique_id()
+    {
+        Id id{};
+        int32_t st = fwa_comm_unique_id(id.data());
+        if (st) throw Error(st, std::string("fwa_comm_unique_id: ") + fwa_last_error_string(nullptr));
+        return id;
+    }
+    Comm(const Device &d, const Id &id, int world, int rank) : d_(d), world_(world), rank_(rank)
+    {
+        d.check(fwa_comm_create(d.raw(), id.data(), world, rank, &h_), "fwa_comm_create");
+    }
+    ~Comm() { fwa_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    int world() const { return world_; }
+    int rank() const { return rank_; }
+    Slab my_slab(uint64_t batch) const { return slab(batch, rank_, world_); }
+    // root's `full` (nullptr elsewhere) -> every rank's `slab_buf`
+    void scatter(int root, const Buffer *full, Buffer &slab_buf, uint32_t fft_len, uint64_t batch, CommandEncoder &enc)
+    {
+        d_.check(fwa_comm_scatter(h_, root, full ? full->raw() : nullptr, slab_buf.raw(), fft_len, batch, enc.raw()), "fwa_comm_scatter");
+    }
+    // every rank's `slab_buf` (e.g. the buffer proc() returned) -> root's `full`
+    void gather(int root, const Buffer &slab_buf, Buffer *full, uint32_t fft_len, uint64_t batch, CommandEncoder &enc)
+    {
+        d_.check(fwa_comm_gather(h_, root, slab_buf.raw(), full ? full->raw() : nullptr, fft_len, batch, enc.raw()), "fwa_comm_gather");
+    }
+    // one send and / or one receive in one group (rank < 0: none); to the own rank only with the matching receive
+    void sendrecv(const Buffer *send, uint64_t send_offset, uint64_t send_bytes, int send_to, Buffer *recv, uint64_t recv_offset,
+                  uint64_t recv_bytes, int recv_from, CommandEncoder &enc)
+    {
+        d_.check(fwa_comm_sendrecv(h_, send ? send->raw() : nullptr, send_offset, send_bytes, send_to, recv ? recv->raw() : nullptr,
+                                   recv_offset, recv_bytes, recv_from, enc.raw()),
+                 "fwa_comm_sendrecv");
+    }
+
+private:
+    const Device &d_;
+    fwa_comm *h_ = nullptr;
+    int world_, rank_;
 };
 
 }  // namespace fft_wgpu
