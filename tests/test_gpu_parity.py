@@ -703,15 +703,16 @@ def test_failed_retune_leaves_the_plan_as_it_was(gpu, oracle):
         assert mx <= REL_TOL and l2 <= REL_TOL, (t, mx, l2)
 
 
-def test_cpp_mirror_replays_reference_example(gpu, tmp_path):
-    """include/fft_wgpu.hpp: C++ replay of examples/basic_inverse2.rs (Onlyinverse + Normalize, n=512,
-    constant input, max error < 1e-5) through the C ABI."""
-    import os
+@pytest.mark.parametrize("example", ["example_basic_inverse2", "example_basic_inverse"])
+def test_cpp_mirror_replays_reference_example(gpu, tmp_path, example):
+    """include/fft_wgpu.hpp: C++ replays of the reference's two asserting tests -- examples/basic_inverse2.rs (Onlyinverse +
+    Normalize) and examples/basic_inverse.rs (Inverse, result in the plan's second buffer, copied to staging): n = 512,
+    constant input, max error < 1e-5 -- through the C ABI."""
     import subprocess
     from conftest import ROOT
     exe = tmp_path / "example"
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tools", "example_basic_inverse2.cpp"),
+                           os.path.join(ROOT, "tools", example + ".cpp"),
                            "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
