@@ -83,6 +83,30 @@ __global__ __launch_bounds__(256, 2) void k_mixed(const char *a, char *b)
 #pragma unroll
     for (int i = 0; i < 32; ++i) __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, ST_SWEEP ? sweep_off : hop_off, i * (ST_SWEEP ? 512 : 2048), 2);
 }
+// block -> chunk maps for the best shape (64-KiB chunk, each wave walks 16 KiB): MAP 0 identity (consecutive chunks go to
+// consecutive XCDs), 1 every XCD owns a contiguous eighth of the buffer, 2 as 1 with the i-th and (i+32)-th workgroup of an XCD
+// (the co-residents of a CU when there are two per CU) on adjacent chunks, 3 as 1 with 4 co-residents (i, i+32, i+64, i+96) adjacent
+template <int MAP>
+__global__ __launch_bounds__(256, 2) void k_mapped(const char *a, char *b)
+{
+    uint32_t blk = blockIdx.x;
+    if (MAP >= 1) {
+        const uint32_t per = gridDim.x >> 3, i = blk >> 3;
+        uint32_t j = i;
+        if (MAP == 2) { const uint32_t g = i & ~63u, r = i & 63u; j = g + (((r & 31u) << 1) | (r >> 5)); }
+        if (MAP == 3) { const uint32_t g = i & ~127u, r = i & 127u; j = g + (((r & 31u) << 2) | (r >> 5)); }
+        blk = (blk & 7u) * per + j;
+    }
+    const uint64_t c = blk;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * 65536, 0, 65536, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * 65536, 0, 65536, 0x00020000);
+    const uint32_t voff = (threadIdx.x >> 6) * 16384 + (threadIdx.x & 63) * 8;
+    v2u x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b64(ra, voff, i * 512, 2);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) __builtin_amdgcn_raw_buffer_store_b64(x[i], rb, voff, i * 512, 2);
+}
 // the same with 16-byte lanes: 1 KiB per wave instruction, U accesses -> each wave walks U KiB
 template <int U, int THREADS, int OCC>
 __global__ __launch_bounds__(THREADS, OCC) void k_sweep16(const char *a, char *b)
@@ -115,7 +139,9 @@ int main(int argc, char **argv)
 #define S8(U, T, O) {"sweep8 per wave, x " #U ", " #T " threads, occ " #O, k_sweep8<U, T, O>, 512u * U * (T / 64), T}
               S8(16, 512, 1), S8(16, 512, 2), S8(16, 1024, 1), S8(32, 128, 4), S8(32, 512, 1), S8(8, 1024, 1),
               {"loads walk, stores hop", k_mixed<true, false>, 65536u}, {"loads hop, stores walk", k_mixed<false, true>, 65536u},
-              {"both hop (64 KiB chunk)", k_mixed<false, false>, 65536u}, {"both walk", k_mixed<true, true>, 65536u}};
+              {"both hop (64 KiB chunk)", k_mixed<false, false>, 65536u}, {"both walk", k_mixed<true, true>, 65536u},
+              {"walk, map 0: identity", k_mapped<0>, 65536u}, {"walk, map 1: XCD-contiguous", k_mapped<1>, 65536u},
+              {"walk, map 2: + CU pairs adjacent", k_mapped<2>, 65536u}, {"walk, map 3: + CU quads adjacent", k_mapped<3>, 65536u}};
     printf("%-34s %12s %12s   (GB/s read+write, %llu MiB each way)\n", "variant", "in place", "out of place", (unsigned long long)(bytes >> 20));
     for (auto &v : vs) {
         float best[2] = {1e30f, 1e30f};
