@@ -201,10 +201,21 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
 // workgroups then streams column tiles whose addresses agree modulo 1 KiB, i.e. they all fall on the same few L2
 // channels.  The swizzle hands each XCD a contiguous run of (transform, tile) indices instead: its 64 resident
 // workgroups are 64 consecutive tiles and cover whole 8-KiB rows.  Grid sizes are multiples of 8 (TILES is).
-__device__ __forceinline__ uint32_t xcd_block(uint32_t swizzle)
+// `pair` (round 4): inside every run of 64, the i-th and (i + 32)-th workgroup of the XCD -- the two residents of one CU when
+// the kernel has the chip to itself -- take ADJACENT tiles (the two 128-byte halves of a 256-byte piece of every row).  Worth
+// 4-5 % to a launch that runs alone (plans with one chain), nothing once a second chain's kernel shares the CUs
+// (profiles/round4/sweep_pair_map_cu_split_negative.txt); needs whole runs of 64 per XCD, else the plain mapping applies.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t swizzle, bool pair = false)
 {
     const uint32_t b = blockIdx.x;
-    return swizzle ? (b & 7u) * (gridDim.x >> 3) + (b >> 3) : b;
+    if (!swizzle) return b;
+    const uint32_t per = gridDim.x >> 3;
+    uint32_t i = b >> 3;
+    if (pair && (per & 63u) == 0) {
+        const uint32_t r = i & 63u;
+        i = (i & ~63u) + (((r & 31u) << 1) | (r >> 5));
+    }
+    return (b & 7u) * per + i;
 }
 
 template <int DIR, int W>
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(32 * W) void k_p1_1m(const v2f *__restrict__ src, v
     v2f *twi = reinterpret_cast<v2f *>(smem + G::XCH_BYTES);
     v2f *two = reinterpret_cast<v2f *>(smem + G::XCH_BYTES + G::TWI_BYTES);
     const uint32_t tid = threadIdx.x;
-    const uint32_t bid = xcd_block(xcd_swizzle & 1u);
+    const uint32_t bid = xcd_block(xcd_swizzle & 1u, (xcd_swizzle & 4u) != 0);
     const uint32_t tile = bid % G::TILES;
     const uint64_t t = bid / G::TILES;  // transform inside the group = ring slot
     if (tid < 512) reinterpret_cast<v4f *>(twi)[tid] = reinterpret_cast<const v4f *>(tw_inner)[tid];
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(32 * W) void k_p2_1m(const v2f *__restrict__ ring, 
     float *xch = reinterpret_cast<float *>(smem);
     v2f *twi = reinterpret_cast<v2f *>(smem + G::XCH_BYTES);
     const uint32_t tid = threadIdx.x;
-    const uint32_t bid = xcd_block(xcd_swizzle & 1u);
+    const uint32_t bid = xcd_block(xcd_swizzle & 1u, (xcd_swizzle & 4u) != 0);
     const uint32_t tile = bid % G::TILES;
     // bit 1: newest ring slots first (the transforms pass 1 wrote last are the likeliest to still sit in the
     // Infinity Cache when this launch starts)
