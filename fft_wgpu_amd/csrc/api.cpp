@@ -1316,9 +1316,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             // in place at group granularity: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
             const int w = (int)plan->tile_w;
             const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
-            // default: XCD-contiguous tiles; with ONE chain also adjacent tiles on the two residents of a CU (bit 2: + 4-5 % for
-            // launches that have the chip to themselves, nothing with a second chain: tile_1m.h xcd_block)
-            const uint32_t swz = plan->xcd_swizzle < 0 ? (plan->istreams.empty() ? 5u : 1u) : (uint32_t)plan->xcd_swizzle;
+            // default: XCD-contiguous tiles + adjacent tiles on the two residents of a CU (bit 2: + 4-8 % for launches that have the
+            // chip to themselves, + 0.6 % with two chains in flight: tile_1m.h xcd_block, profiles/round4/sweep_pair_map_two_chains.jsonl)
+            const uint32_t swz = plan->xcd_swizzle < 0 ? 5u : (uint32_t)plan->xcd_swizzle;
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 // ring region of this chain: transform i -> slot i (ring_rotate > 1, laboratory: successive groups of a
                 // chain walk through ring_rotate such regions)
@@ -1432,7 +1432,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "tile_w") *value = plan->tile_w;
-    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? (plan->istreams.empty() ? 5 : 1) : 0) : plan->xcd_swizzle;
+    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? 5 : 0) : plan->xcd_swizzle;
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;

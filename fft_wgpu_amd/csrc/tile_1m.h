@@ -203,8 +203,9 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
 // workgroups are 64 consecutive tiles and cover whole 8-KiB rows.  Grid sizes are multiples of 8 (TILES is).
 // `pair` (round 4): inside every run of 64, the i-th and (i + 32)-th workgroup of the XCD -- the two residents of one CU when
 // the kernel has the chip to itself -- take ADJACENT tiles (the two 128-byte halves of a 256-byte piece of every row).  Worth
-// 4-5 % to a launch that runs alone (plans with one chain), nothing once a second chain's kernel shares the CUs
-// (profiles/round4/sweep_pair_map_cu_split_negative.txt); needs whole runs of 64 per XCD, else the plain mapping applies.
+// 4-8 % to a launch that runs alone (plans with one chain) and 0.6 % once a second chain's kernel shares the CUs
+// (profiles/round4/sweep_pair_map_cu_split_negative.txt, sweep_pair_map_two_chains.jsonl); needs whole runs of 64 per XCD,
+// else the plain mapping applies.
 __device__ __forceinline__ uint32_t xcd_block(uint32_t swizzle, bool pair = false)
 {
     const uint32_t b = blockIdx.x;

@@ -202,9 +202,9 @@ def test_config_c2_n1m_batch1(gpu, oracle):
 
 GEOMETRIES_16 = (dict(tile_w=16), dict(tile_w=16, xcd_swizzle=0), dict(tile_w=16, group=5, streams=3), dict(group=7, streams=1),
                  dict(group=32, streams=2), dict(group=3, streams=4),
-                 # round 4: the pair map (xcd_swizzle bit 2: the two residents of a CU take adjacent tiles) -- the default of
-                 # one-chain plans; active when an XCD gets whole runs of 64 tiles (group 16, 8), plain mapping otherwise (group 7, 20)
-                 dict(group=16, streams=1), dict(group=8, streams=1), dict(group=16, streams=2, xcd_swizzle=5),
+                 # round 4: the pair map (xcd_swizzle bit 2: the two residents of a CU take adjacent tiles) -- the default (5);
+                 # active when an XCD gets whole runs of 64 tiles (group 16, 8), plain mapping otherwise (group 7, 20)
+                 dict(group=16, streams=1), dict(group=8, streams=1), dict(group=16, streams=2, xcd_swizzle=1),
                  dict(group=20, streams=1, xcd_swizzle=7), dict(group=16, streams=1, xcd_swizzle=1))
 GEOMETRIES_32 = (dict(tile_w=32), dict(tile_w=32, group=8, streams=2, xcd_swizzle=0), dict(tile_w=32, group=7, streams=1),
                  dict(tile_w=32, group=32, streams=2))
