@@ -688,6 +688,18 @@ static fwa_buf *result_buffer(fwa_plan *p)
     return (p->lg % 2 == 0) ? p->src : p->second;
 }
 
+// Block -> tile map of the tiled plans' kernels (xcd_map, device_common.h) when the caller has not set "xcd_swizzle": measured per
+// size at the 32-GiB footprint, three interleaved runs (profiles/round4/sweep_tiled_block_maps.jsonl): the k_colsw plans gain 2-4 %
+// from XCD-contiguous runs (2^17 .. 2^19: bit 0; 2^16 and 1024 x 2048: with the CU pairs, bits 0 + 2); 2^22 and up lose 1-10 %.
+static uint32_t tiled_swizzle_default(const fwa_plan *p)
+{
+    if (p->lf[2]) return 0u;
+    if (p->colsw && p->lg == 16) return 5u;
+    if (p->colsw && p->lg >= 17 && p->lg <= 19) return 1u;
+    if (p->lg == 21 && p->lf[0] == 10 && p->lf[1] == 11) return 5u;
+    return 0u;
+}
+
 // Run `body(group index, stream, chain index)` for every group, alternating over the plan's internal streams,
 // forked from and joined back to the caller's stream with events.
 template <class Body>
@@ -1355,7 +1367,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 v2f *slab = plan->ring + (uint64_t)c * G * N;
                 fwa::TileArgs ta{};
-                ta.xcd_swizzle = plan->xcd_swizzle < 0 ? 0u : (uint32_t)plan->xcd_swizzle;
+                ta.xcd_swizzle = plan->xcd_swizzle < 0 ? tiled_swizzle_default(plan) : (uint32_t)plan->xcd_swizzle;
                 // pass A
                 uint32_t cw = pass_cw(plan, 0);
                 ta.in = a + g * G * N; ta.out = slab; ta.tw = tb.tw_l[0]; ta.tw_lo = tb.tw_lo1; ta.tw_hi = tb.tw_hi1;
@@ -1432,7 +1444,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "tile_w") *value = plan->tile_w;
-    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? 5 : 0) : plan->xcd_swizzle;
+    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? 5 : (plan->path == PATH_TILED ? (int64_t)tiled_swizzle_default(plan) : 0)) : plan->xcd_swizzle;
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;

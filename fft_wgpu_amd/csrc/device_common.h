@@ -41,6 +41,25 @@ __device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, uint3
 }
 
 
+// XCD-aware block -> tile mapping shared by the pass kernels (cdna_hip_programming.md T1).  Blocks are dealt round-robin over the
+// 8 XCDs.  bit 0: every XCD takes a contiguous run of tile indices instead of one residue class mod 8 (its resident workgroups
+// then cover whole rows).  bit 2 (with bit 0; round 4): inside every run of 64, the i-th and (i + 32)-th workgroup of the XCD --
+// the two residents of one CU when the kernel runs two workgroups per CU and has the chip to itself -- take ADJACENT tiles: their
+// strided pieces are the two halves of a piece twice as long (profiles/round4/sweep_pair_map_cu_split_negative.txt).  Needs a
+// grid that is a multiple of 8 (launchers clear the bits otherwise) and, for bit 2, whole runs of 64 per XCD.
+__device__ __forceinline__ uint32_t xcd_map(uint32_t swizzle)
+{
+    const uint32_t b = blockIdx.x;
+    if (!(swizzle & 1u)) return b;
+    const uint32_t per = gridDim.x >> 3;
+    uint32_t i = b >> 3;
+    if ((swizzle & 4u) && (per & 63u) == 0) {
+        const uint32_t r = i & 63u;
+        i = (i & ~63u) + (((r & 31u) << 1) | (r >> 5));
+    }
+    return (b & 7u) * per + i;
+}
+
 template <int N>
 __device__ __forceinline__ v2f tw_lookup(const v2f *__restrict__ tw, uint32_t e)  // W_N^e, 0 <= e < N
 {

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(512) void k_p1_gen(const v2f *__restrict__ src, v2f
     v2f *twi = reinterpret_cast<v2f *>(smem + G::XCH_BYTES);
     v2f *two = reinterpret_cast<v2f *>(smem + G::XCH_BYTES + G::TWI_BYTES);
     const uint32_t tid = threadIdx.x;
-    const uint32_t bid = xcd_block(xcd_swizzle & 1u);
+    const uint32_t bid = xcd_map(xcd_swizzle);
     const uint32_t tiles = pitch >> 4;
     const uint32_t tile = bid % tiles;
     const uint64_t t = bid / tiles;

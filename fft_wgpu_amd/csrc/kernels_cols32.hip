@@ -29,8 +29,7 @@ __global__ __launch_bounds__(1024, 4) void k_cols32(const v2f *__restrict__ in, 
     float *lds = reinterpret_cast<float *>(smem);
     v2f *two = reinterpret_cast<v2f *>(smem + G::LDS_BYTES);
     const uint32_t tid = threadIdx.x;
-    const uint32_t b0 = blockIdx.x;
-    const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
+    const uint32_t bid = xcd_map(xcd_swizzle);
     const uint32_t tiles = pitch >> LGCW;
     const uint32_t tile = bid % tiles;
     const uint64_t bt = bid / tiles;
@@ -120,8 +119,7 @@ __global__ __launch_bounds__(512, 4) void k_colsw(const v2f *__restrict__ in, v2
     v2f *tq = reinterpret_cast<v2f *>(smem + G::LDS_BYTES);  // Bq[R1][CW], then Bb[B1][CW]
     v2f *tb = tq + R1 * CW;
     const uint32_t tid = threadIdx.x;
-    const uint32_t b0 = blockIdx.x;
-    const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
+    const uint32_t bid = xcd_map(xcd_swizzle);
     const uint32_t tiles = pitch >> LGCW;
     const uint32_t tile = bid % tiles;
     const uint64_t bt = bid / tiles;

@@ -57,8 +57,7 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     const uint32_t tid = threadIdx.x;
-    const uint32_t b0 = blockIdx.x;
-    const uint32_t bid = (xcd_swizzle & 1u) ? (b0 & 7u) * (gridDim.x >> 3) + (b0 >> 3) : b0;
+    const uint32_t bid = xcd_map(xcd_swizzle);
     const uint32_t tiles = n1 >> LGRW;
     const uint32_t tile = bid % tiles;
     const uint64_t bt = bid / tiles;

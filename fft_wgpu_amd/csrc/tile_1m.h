@@ -196,27 +196,12 @@ __device__ __forceinline__ void p2_tile(const v2f *in, v2f *out, uint32_t tile, 
     FWA_STAMP_B(3);
 }
 
-// XCD-aware block -> tile mapping (cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, so
-// with tile = blockIdx % TILES an XCD only ever holds tiles of the same residue mod 8: every one of its resident
-// workgroups then streams column tiles whose addresses agree modulo 1 KiB, i.e. they all fall on the same few L2
-// channels.  The swizzle hands each XCD a contiguous run of (transform, tile) indices instead: its 64 resident
-// workgroups are 64 consecutive tiles and cover whole 8-KiB rows.  Grid sizes are multiples of 8 (TILES is).
-// `pair` (round 4): inside every run of 64, the i-th and (i + 32)-th workgroup of the XCD -- the two residents of one CU when
-// the kernel has the chip to itself -- take ADJACENT tiles (the two 128-byte halves of a 256-byte piece of every row).  Worth
-// 4-8 % to a launch that runs alone (plans with one chain) and 0.6 % once a second chain's kernel shares the CUs
-// (profiles/round4/sweep_pair_map_cu_split_negative.txt, sweep_pair_map_two_chains.jsonl); needs whole runs of 64 per XCD,
-// else the plain mapping applies.
+// XCD-aware block -> tile mapping: xcd_map (device_common.h).  Bit 0 hands each XCD a contiguous run of (transform, tile)
+// indices: its 64 resident workgroups are 64 consecutive tiles and cover whole 8-KiB rows (+ 2 %); bit 2 puts the two residents
+// of a CU on adjacent tiles (+ 4-8 % for a launch that runs alone, + 0.6 % with two chains: sweep_pair_map_two_chains.jsonl).
 __device__ __forceinline__ uint32_t xcd_block(uint32_t swizzle, bool pair = false)
 {
-    const uint32_t b = blockIdx.x;
-    if (!swizzle) return b;
-    const uint32_t per = gridDim.x >> 3;
-    uint32_t i = b >> 3;
-    if (pair && (per & 63u) == 0) {
-        const uint32_t r = i & 63u;
-        i = (i & ~63u) + (((r & 31u) << 1) | (r >> 5));
-    }
-    return (b & 7u) * per + i;
+    return xcd_map((swizzle & 1u) | (pair ? 4u : 0u));
 }
 
 template <int DIR, int W>

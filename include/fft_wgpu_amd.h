@@ -188,7 +188,8 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "launches_per_exec", "scratch_bytes", "tables_shared" (other holders of this plan's twiddle tables),
  *   "group" (transforms per launch), "streams" (chain streams the groups alternate over, <= 16)   [paths 1, 7]
  *   "xcd_swizzle" (XCD-aware block -> tile mapping: bit 0 = every XCD takes a contiguous run of tiles; path 1 also bit 2 =
- *                  the two resident workgroups of a CU take adjacent tiles; path 1 defaults to 5, path 7 to 0)        [paths 1, 7]
+ *                  the two resident workgroups of a CU take adjacent tiles; path 1 defaults to 5, path 7 per size: 5 at 2^16 and
+ *                  2^21, 1 at 2^17 .. 2^19, 0 elsewhere)                                                              [paths 1, 7]
  *   "colsw" (tiled plans whose first factor is 256 / 512: 1 = k_colsw, 256 x 64 / 512 x 32 column tiles, as pass A -- the
  *   default in the many-transform regime at 2^16..2^19 and 2^24..2^28 -- 0 = the generic tile kernel),
  *   "tile_ring" (k_colsw followed by the row kernel: 1 = tile-contiguous ring slab (default), 0 = matrix layout),

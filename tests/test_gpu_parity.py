@@ -232,6 +232,24 @@ def test_n1m_pipeline_geometries_are_bit_identical(gpu, oracle):
     _n1m_geometries_body(gpu, oracle, GEOMETRIES_16)
 
 
+@pytest.mark.parametrize("lg,batch", [(16, 600), (17, 300), (19, 70), (21, 19), (22, 9), (24, 3)])
+def test_tiled_block_maps_are_bit_identical(gpu, oracle, lg, batch):
+    """Key "xcd_swizzle" on the tiled plans (xcd_map, device_common.h: bit 0 = every XCD takes a contiguous run of tiles, bit 2 =
+    the two residents of a CU take adjacent tiles; per-size defaults since round 4: 5 at 2^16 / 2^21, 1 at 2^17 .. 2^19, 0 elsewhere).
+    A map only decides which workgroup takes which tile: every value gives the same bits, with full groups (runs of 64 per XCD:
+    the pair map is active), ragged last groups (plain mapping) and both chains; the default agrees with the f64 DFT."""
+    fw, dev, queue = gpu
+    n = 1 << lg
+    x = oracle.gen_input(n, batch, first_transform=lg)
+    ref, _, plan = _run(fw, dev, queue, "Forward", x, n)
+    assert plan.get("path") == 7 and plan.get("xcd_swizzle") == {16: 5, 17: 1, 19: 1, 21: 5}.get(lg, 0)
+    _check(oracle, ref[:2 * n], oracle.dft_f64(x[:2 * n], n, -1), n)
+    for swz in (0, 1, 5):
+        y, _, p = _run(fw, dev, queue, "Forward", x, n, xcd_swizzle=swz)
+        assert p.get("xcd_swizzle") == swz
+        assert np.array_equal(y.view(np.uint64), ref.view(np.uint64)), (lg, swz)
+
+
 def test_n1m_matches_literal_recurrence(gpu, oracle):
     fw, dev, queue = gpu
     n = 1 << 20
