@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r4pair; mkdir -p $O; rm -f $O/ab.txt
-for v in pair1 pair_only_P1 pair_only_P2; do FWA_LAB_LIBRARY=$PWD/tools/variants/$v.so timeout -k 10 200 python3 tools/variants/walk_check.py; done
+for v in pair1 pair_only_P1 pair_only_P2; do FWA_LAB_LIBRARY=$PWD/tools/variants/$v.so timeout -k 10 200 python3 tools/variant_parity_check.py; done
 for rep in 1 2 3; do
   timeout -k 10 200 python3 tools/sweep.py --lg 20 --batch 4096 --reps 5 --set "" --set "streams=1" | sed 's/^/shipped /' >> $O/ab.txt
   for v in pair1 pair_only_P1 pair_only_P2; do
