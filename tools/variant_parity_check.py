@@ -1,4 +1,5 @@
-"""tools/variant_parity_check.py -- parity of a VARIANT library of the 2^20 pipeline (an experiment built with extra -D flags from a\npatch under profiles/round4/*.patch and loaded through FWA_LAB_LIBRARY): forward against the f64 DFT, round trip, two geometries."""
+"""tools/variant_parity_check.py -- parity of a VARIANT library of the 2^20 pipeline (an experiment built with extra -D flags from a
+patch under profiles/round4/*.patch and loaded through FWA_LAB_LIBRARY): forward against the f64 DFT, round trip, two geometries."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
