@@ -3,28 +3,46 @@
 
 One step = one `Forward.proc` over the whole per-GPU batch (synthetic interleaved complex fp32,
 generated on the device, resident in HBM before the clock starts).  One process per GPU; batches
-shard as independent slabs (no data-path collective), so scaling is "weak": every rank runs the
-full 4096-transform slab (config C4 = 4096 per GPU x 8).
+shard as independent slabs (no data-path collective; reference src/kernel/fft4.wgsl:21-23: one
+`offset` per workgroup), so scaling is "weak": every rank runs the full 4096-transform slab
+(config C4 = 4096 per GPU x 8).
 
-Launch: `python bench.py --gpus N` starts its own N ranks (child processes, started before anything touches a
-GPU) when WORLD_SIZE is not set; under torchrun it uses the environment it is given.  It refuses to run with
-fewer visible devices than --gpus.
+Launch: under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) it uses
+the environment it is given (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Without one, `python bench.py --gpus N`
+starts its own N ranks -- fresh child processes, started before anything touches a GPU -- and supervises them:
+the first child that exits non-zero takes its siblings down (SIGTERM, then SIGKILL) and the parent returns that
+status, so a dead rank never leaves the others parked in a barrier.  It refuses to run with fewer visible
+devices than --gpus.
 
-Order of one run (rank 0, N = 1): the CPU baseline first (the oracle's restatement of the reference algorithm on the host
-cores, ~12 s, nothing on the GPU yet), then the GPU phase -- warm-up, the K timed steps, the stream-ceiling calibration
-and a 100-exec spread leg (HIP events only, not part of `value`); the line carries "gpu_phase_s", the wall time of
-that phase, so that a utilisation sampler's window can be compared with it.
+Order of one run: rank 0 times the CPU baseline first (the oracle's restatement of the reference algorithm on
+the host cores, ~12 s, nothing on the GPU yet; the other ranks wait in the rendezvous, timeout 120 s), then the
+GPU phase -- warm-up, the K timed steps, the stream-ceiling calibration and a 100-exec spread leg on rank 0 (HIP
+events only, not part of `value`), and for N > 1 the slab-movement leg (below).  The line carries "gpu_phase_s".
 
 Timing: K steps inside barrier + torch.cuda.synchronize() brackets, wall clock, MAX over ranks.
 Because a forward FFT multiplies the RMS by 2^10 and `proc` works in place, the K steps run in
 chunks of <= 8 with the input regenerated (at scale 2^-40) between chunks, outside the brackets,
 so fp32 never overflows to inf/NaN (benchmarks on degenerate data are not representative).
-HIP events on the launch stream time each step for the roofline object.
+HIP events on the launch stream time each step for the roofline object; for N > 1 the line carries every rank's
+own time ("per_rank_ms": its wall clock between the opening barrier and its own synchronize, before the closing
+barrier) and `roofline` is that of the SLOWEST rank.
+
+Movement (N > 1, SURVEY.md 8(e): "reported as a separate line", never part of `value`): after the timed steps
+rank 0 scatters one slab of MOVE_TRANSFORMS transforms to every rank and gathers them back through the library's
+own communicator (`fwa_comm_scatter` / `fwa_comm_gather`: grouped RCCL send / receive over xGMI), timed with HIP
+events; a watchdog prints the line without it if the exchange does not finish in MOVE_TIMEOUT_S.
+
+Rehearsal (FWA_BENCH_REHEARSAL=1, never set by the driver): every rank runs on device 0 and the process group is
+"gloo" (RCCL refuses two ranks on one device), so the whole N > 1 control flow -- rendezvous, barriers, MAX /
+all-gather, rank-0-only printing, slab offsets -- executes on a one-GPU box.  The line says `"rehearsal": true`
+in `config`, and its value is N ranks sharing ONE GPU: not a measurement of anything.
 """
 import argparse
 import json
 import os
+import signal
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +51,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 16      # one 8-B read + one 8-B write per complex sample
 CHUNK = 8                       # steps between input regenerations (2^-40 * 2^(10*8) stays finite)
+RENDEZVOUS_TIMEOUT_S = 120      # init_process_group / collectives: a missing rank is an error after this long
+MOVE_TRANSFORMS = 256           # slab moved per rank by the movement leg (2 GiB at N = 2^20)
+MOVE_TIMEOUT_S = 90
 
 
 def usable_cores():
@@ -47,6 +68,48 @@ def usable_cores():
     return n
 
 
+def rehearsal():
+    return os.environ.get("FWA_BENCH_REHEARSAL") == "1"
+
+
+def supervise(procs, poll_s=0.1, grace_s=5.0, log=sys.stderr):
+    """Wait for the ranks in `procs` (subprocess.Popen).  All exit 0 -> 0.  The first one that exits non-zero (or is
+    killed by a signal) ends the run: its siblings get SIGTERM, after `grace_s` SIGKILL, and its status (signal n ->
+    128 + n) is returned -- the survivors would otherwise sit in a barrier until the process-group timeout."""
+    alive = list(procs)
+    rc = 0
+    while alive and rc == 0:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0:
+                rc = r if r > 0 else 128 - r
+                print(f"bench.py: rank {procs.index(p)} exited with status {r}; stopping the other {len(alive)} rank(s)",
+                      file=log, flush=True)
+                break
+        if alive and rc == 0:
+            time.sleep(poll_s)
+    if alive:
+        for p in alive:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+        deadline = time.monotonic() + grace_s
+        for p in alive:
+            try:
+                p.wait(max(0.0, deadline - time.monotonic()))
+            except Exception:
+                try:
+                    p.kill()
+                except OSError:
+                    pass
+                p.wait()
+    return rc
+
+
 def self_launch(args):
     """No launcher environment and --gpus N > 1: start N ranks of this script (one process per GPU) and relay
     their exit status.  Runs before any HIP call; torch.cuda.device_count() does not initialise the GPU."""
@@ -54,7 +117,8 @@ def self_launch(args):
     import subprocess
     import torch
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    need = 1 if rehearsal() else args.gpus
+    if visible < need:
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} device(s) visible; refusing to "
                          f"report a {args.gpus}-GPU figure from fewer GPUs")
     with socket.socket() as sk:
@@ -65,10 +129,18 @@ def self_launch(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    raise SystemExit(rc)
+
+    def on_signal(signum, _frame):  # the parent is told to stop: the ranks must not outlive it
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.terminate()
+                except OSError:
+                    pass
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    raise SystemExit(supervise(procs))
 
 
 def main():
@@ -83,11 +155,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spread", type=int, default=100, help="extra execs timed one by one after the K steps (0 = off)")
+    ap.add_argument("--no-movement", action="store_true", help="N > 1: skip the slab scatter / gather leg")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)  # never returns
 
+    import datetime
     import torch
     import torch.distributed as dist
 
@@ -96,25 +170,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("FWA_BENCH_FORCE_DIST") == "1"  # the env knob exercises the N>1 code path on one GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", str(rank))
-        os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if os.environ.get("FWA_BENCH_FAIL_RANK") == str(rank):   # test knob: this rank dies before the rendezvous
+        print(f"bench.py: rank {rank} exits on request (FWA_BENCH_FAIL_RANK)", file=sys.stderr, flush=True)
+        sys.exit(3)
+    rehearse = rehearsal() and world > 1
+    device_index = 0 if rehearse else local_rank          # rehearsal: every rank shares device 0
+    if torch.cuda.device_count() <= device_index:
+        raise SystemExit(f"bench.py: rank {rank} has no device {device_index} ({torch.cuda.device_count()} visible)")
 
-    import fft_wgpu_amd as fw
-    from fft_wgpu_amd import sharding
-
-    # CPU baseline BEFORE anything runs on the GPU (rank 0, N = 1 only): afterwards the run is one contiguous GPU phase
+    # CPU baseline on rank 0 BEFORE the rendezvous and before anything runs on the GPU: afterwards the run is one
+    # contiguous GPU phase.  The other ranks wait for rank 0's store inside init_process_group (RENDEZVOUS_TIMEOUT_S).
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
         import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
         cores = usable_cores()
         cb = max(cores, 8)
@@ -122,10 +189,42 @@ def main():
         cpu = {"value": sps / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": "port",
                "sample": f"{cb} transforms of N={args.fft_len} (same generator, seed 0x5EED), best of {reps} repetitions, "
                          f"OpenMP over transforms; CPU restatement of the reference radix-2 Stockham algorithm; timed "
-                         f"before the GPU phase"}
-    t_gpu_phase = time.perf_counter()
+                         f"on rank 0 before the GPU phase"}
 
-    got = fw.prepare_gpu(local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(device_index)
+    use_dist = world > 1 or os.environ.get("FWA_BENCH_FORCE_DIST") == "1"  # the env knob exercises the N>1 code path on one GPU
+    backend = "gloo" if rehearse else "nccl"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        kw = {} if backend == "gloo" else {"device_id": torch.device("cuda", device_index)}
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S), **kw)
+    coll_dev = torch.device("cpu") if backend == "gloo" else torch.device("cuda", device_index)
+
+    def dist_barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[device_index])
+        else:
+            dist.barrier()
+
+    def all_gather_f64(x):
+        """every rank's scalar, in rank order"""
+        if not use_dist:
+            return [float(x)]
+        out = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([x], dtype=torch.float64, device=coll_dev))
+        return [float(v.item()) for v in out]
+
+    t_gpu_phase = time.perf_counter()
+    import fft_wgpu_amd as fw
+    from fft_wgpu_amd import sharding
+
+    got = fw.prepare_gpu(device_index)
     if got is None:
         raise SystemExit("no usable gfx950 device")
     dev, queue = got
@@ -145,11 +244,14 @@ def main():
         dev.fill_synthetic(buf, n, first_transform=first, scale=2.0 ** -40, encoder=enc)
         enc.synchronize()
 
-    def barrier():
+    def local_sync():
         enc.synchronize()
         torch.cuda.synchronize()
+
+    def barrier():
+        local_sync()
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist_barrier()
 
     regen()
     for _ in range(args.warmup):
@@ -157,7 +259,8 @@ def main():
     barrier()
 
     ev = [(fw.Event(dev), fw.Event(dev)) for _ in range(args.steps)]
-    wall = 0.0
+    wall = 0.0        # between the brackets, closing barrier included: MAX over ranks -> `value`
+    wall_own = 0.0    # this rank's own work: opening barrier -> its own synchronize
     done = 0
     while done < args.steps:
         k = min(CHUNK, args.steps - done)
@@ -168,23 +271,32 @@ def main():
             ev[done + i][0].record(enc)
             plan.proc(enc)
             ev[done + i][1].record(enc)
-        barrier()
+        local_sync()
+        t1 = time.perf_counter()
+        if use_dist:
+            dist_barrier()
         wall += time.perf_counter() - t0
+        wall_own += t1 - t0
         done += k
     step_ms_events = [a.elapsed_ms(b) for a, b in ev]
+    ev_ms = sum(step_ms_events) / len(step_ms_events)
 
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
+    per_rank_ms = all_gather_f64(wall_own / args.steps * 1e3)
+    per_rank_ev_ms = all_gather_f64(ev_ms)
+    per_rank_first = all_gather_f64(float(first))
 
     # calibration on the same stream, same run (rank 0): what a single streaming pass sustains on this box --
     #  * in place (every line read, then written back: the traffic of the one-launch FFT kernels; fwa_calib_copy with
     #    dst == src runs the normalize kernel: one workgroup per 64-KiB chunk, every wave walks 16 KiB, 32 nt loads in flight),
     #  * out of place (8 GiB -> another 8 GiB, the same launch shape).
+    # With N > 1 in rehearsal the ranks share one GPU: calibration figures would mean nothing and are skipped.
     copy_gbps = stream_gbps = None
     spread = single_pass = None
-    if rank == 0:
+    if rank == 0 and not rehearse:
         def rate(dst, src, nb, reps=3):
             dev.calib_copy(dst, src, nb, encoder=enc)
             a, b = fw.Event(dev), fw.Event(dev)
@@ -235,14 +347,14 @@ def main():
             spread = {"execs": len(sp), "ms_p10": sp[len(sp) // 10], "ms_p50": sp[len(sp) // 2], "ms_p90": sp[(len(sp) * 9) // 10],
                       "ms_min": sp[0], "ms_max": sp[-1]}
     enc.synchronize()
-    gpu_phase_s = time.perf_counter() - t_gpu_phase
 
-    if rank == 0:
+    def build_line(movement):
         samples_per_step = n * batch * world
         ms_per_step = wall_max / args.steps * 1e3
         value = samples_per_step / (wall_max / args.steps) / 1e9
-        ev_ms = sum(step_ms_events) / len(step_ms_events)
-        achieved = ALGO_BYTES_PER_SAMPLE * n * batch / (ev_ms * 1e-3) / 1e9
+        slow = max(range(world), key=lambda r: per_rank_ev_ms[r]) if use_dist else 0
+        slow_ms = per_rank_ev_ms[slow] if use_dist else ev_ms       # roofline of the slowest rank's GPU
+        achieved = ALGO_BYTES_PER_SAMPLE * n * batch / (slow_ms * 1e-3) / 1e9
         # Figures that cannot be measured inside the timed run (PMC counters need their own rocprofv3 passes; the
         # linear-stream floors are probe programs): read from profiles/bench_reference.json, each with its source.
         traffic = traffic_source = floors = isolated = None
@@ -262,9 +374,9 @@ def main():
         group = plan.get("group")
         # one exec = `launches` kernel launches (k_p1_1m then k_p2_1m per group of transforms) on `chains` concurrent
         # internal streams; a launch carries one pass over `group` transforms = half of their algorithmic bytes.
-        avg_launch_us = ev_ms * 1e3 * chains / launches
+        avg_launch_us = slow_ms * 1e3 * chains / launches
         launch_bytes = ALGO_BYTES_PER_SAMPLE * n * group // 2
-        line = {
+        return {
             "metric": "Gsamples/s, 1-D c2c fp32 forward FFT N=2^20 batch=4096 per GPU",
             "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -272,18 +384,23 @@ def main():
             "config": {"workload": f"1-D c2c fp32 FFT N={n} batch={batch} per GPU (BASELINE.json configs[2]"
                                    f"{'; configs[3] shape' if world > 1 else ''})",
                        "fft_len": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective",
+                       "rehearsal": bool(rehearse),
                        "dist_backend": (dist.get_backend() if use_dist else None),
                        "dist_world_size": (dist.get_world_size() if use_dist else None),
+                       "slab_first_transform_per_rank": [int(v) for v in per_rank_first],
                        "chain_streams_checked": dev.stats().get("chain_checks"), "chain_streams_rejected": dev.stats().get("chain_rejects"),
                        "plan_path": plan.get("path"), "group": group, "streams": chains,
                        "tile_w": plan.get("tile_w"), "launches_per_step": launches,
                        "scratch_bytes": plan.get("scratch_bytes")},
+            # every rank's own step time (wall clock, opening barrier -> its own synchronize) and HIP-event exec time
+            "per_rank_ms": per_rank_ms, "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": max(per_rank_ms),
+            "per_rank_hip_event_ms": per_rank_ev_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBPS, "rank": slow, "traffic": traffic, "traffic_source": traffic_source,
                          "measured_floors": floors, "isolated_kernel_us": isolated,
                          "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group "
                                    "of transforms, alternating over the chains)",
-                         "ms_per_exec_hip_events": ev_ms, "ms_min": min(step_ms_events),
+                         "ms_per_exec_hip_events": slow_ms, "ms_min": min(step_ms_events),
                          # rocprofv3's mean duration over the k_p1_1m and k_p2_1m launches must equal avg_launch_us
                          # (launches of different chains overlap: sum of durations / chains = exec time)
                          "per_launch": {"launches": launches, "chains": chains, "avg_launch_us": avg_launch_us,
@@ -298,12 +415,79 @@ def main():
                          "single_pass_reference_same_run": single_pass,
                          "exec_spread_hip_events": spread},
             "cpu_baseline": cpu,
-            "gpu_phase_s": gpu_phase_s,
+            "movement": movement,
+            "gpu_phase_s": time.perf_counter() - t_gpu_phase,
         }
-        print(json.dumps(line), flush=True)
+
+    # ---- movement leg (N > 1; never part of `value`) -------------------------------------------------------------------
+    movement = None
+    if use_dist and not args.no_movement:
+        if rehearse:
+            movement = {"skipped": "rehearsal: RCCL refuses two ranks on one device (fwa_comm_* needs one GPU per rank)"}
+        else:
+            mt = min(MOVE_TRANSFORMS, batch // (world + 1))     # full batch (world slabs) + this rank's slab fit `buf`
+            if mt < 1:
+                movement = {"skipped": f"batch {batch} per GPU is too small to carve {world} + 1 slabs out of the buffer"}
+            else:
+                finished = threading.Event()
+
+                def give_up():   # the exchange hangs: the timed figures are still good -- print them and leave
+                    if finished.is_set():
+                        return
+                    if rank == 0:
+                        print(json.dumps(build_line({"error": f"fwa_comm scatter / gather did not finish in "
+                                                              f"{MOVE_TIMEOUT_S} s; the line is complete without it"})), flush=True)
+                    else:
+                        time.sleep(3.0)   # rank 0 prints first; a launcher tears the job down at the first exit
+                    os._exit(0)           # status 0 on every rank: the failure is in the line, the measurement stands
+                dog = threading.Timer(MOVE_TIMEOUT_S, give_up)
+                dog.daemon = True
+                dog.start()
+                try:
+                    movement = move_slabs(fw, dist, torch, dev, enc, buf, n, mt, rank, world, coll_dev)
+                except Exception as e:   # a status code from the library: report it, keep the line
+                    movement = {"error": f"{type(e).__name__}: {e}"}
+                finished.set()
+                dog.cancel()
+
+    if rank == 0:
+        print(json.dumps(build_line(movement)), flush=True)
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        dist_barrier()
         dist.destroy_process_group()
+
+
+def move_slabs(fw, dist, torch, dev, enc, buf, n, mt, rank, world, coll_dev):
+    """Rank 0 scatters `mt` transforms to every rank and gathers them back through fwa_comm_* (RCCL send / receive,
+    grouped), HIP events on the launch stream of each rank; the rates are bytes that LEAVE / ENTER rank 0 over xGMI
+    (its own slab is a local copy) divided by the slowest rank's time.  Buffers are views of the benchmark buffer:
+    on rank 0 the first world * mt transforms are the full batch and the next mt its slab; elsewhere the first mt."""
+    from fft_wgpu_amd import sharding
+    tb = 8 * n
+    uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(sharding.Comm.unique_id()), dtype=torch.uint8).to(coll_dev)
+    dist.broadcast(uid, 0)
+    comm = sharding.Comm(dev, bytes(uid.cpu().numpy().tobytes()), world, rank)
+    full = dev.wrap_buffer(buf.device_ptr, world * mt * tb) if rank == 0 else None
+    slab = dev.wrap_buffer(buf.device_ptr + (world * mt * tb if rank == 0 else 0), mt * tb)
+    gbatch = world * mt
+    out = {"transforms_per_rank": mt, "bytes_per_rank": mt * tb, "root": 0, "api": "fwa_comm_scatter / fwa_comm_gather"}
+    for name, call in (("scatter", lambda: comm.scatter(full, slab, n, gbatch, root=0, encoder=enc)),
+                       ("gather", lambda: comm.gather(slab, full, n, gbatch, root=0, encoder=enc))):
+        call()                      # first exchange: connection set-up of the communicator
+        enc.synchronize()
+        a, b = fw.Event(dev), fw.Event(dev)
+        a.record(enc)
+        call()
+        b.record(enc)
+        ms = torch.tensor([a.elapsed_ms(b)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        ms = float(ms.item())
+        out[name + "_ms"] = ms
+        out[name + "_GBps"] = (world - 1) * mt * tb / (ms * 1e-3) / 1e9 if world > 1 else None
+    comm.destroy()
+    return out
 
 
 if __name__ == "__main__":

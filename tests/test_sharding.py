@@ -181,3 +181,28 @@ def test_bench_rank_slab_is_sharding_slab():
     for world in (1, 2, 4, 8):
         for r in range(world):
             assert slab(4096 * world, r, world) == (r * 4096, (r + 1) * 4096)
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """bench.py's own launcher (`--gpus N` without a launcher environment) supervises its ranks: the first one that exits
+    non-zero ends the run, siblings get SIGTERM and -- if they ignore it -- SIGKILL, and its status is returned; ranks
+    that all exit 0 give 0.  Stand-in children here (no GPU); the real thing runs in tests/test_gpu_bench.py."""
+    import io
+    import subprocess
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    sleeper = "import time; time.sleep(120)"
+    stubborn = "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(120)"
+    procs = [subprocess.Popen([sys.executable, "-c", sleeper]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"]),
+             subprocess.Popen([sys.executable, "-c", stubborn])]
+    log = io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.supervise(procs, grace_s=1.0, log=log)
+    assert rc == 3 and time.monotonic() - t0 < 20.0
+    assert [p.returncode for p in procs] == [-15, 3, -9]
+    assert "rank 1 exited with status 3" in log.getvalue()
+    assert bench.supervise([subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]) == 0
+    killed = subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"])
+    assert bench.supervise([killed], log=io.StringIO()) == 128 + 9
