@@ -72,6 +72,8 @@ _SIGNATURES = {
     "fwa_plan_get_i64": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "fwa_plan_set_i64": (_I32, [_P, ctypes.c_char_p, ctypes.c_int64]),
     "fwa_slab": (_I32, [_U64, _I32, _I32, ctypes.POINTER(_U64), ctypes.POINTER(_U64)]),
+    "fwa_comm_pieces": (_I32, [_U64, _U32, _I32, _I32, _I32, ctypes.POINTER(_U64), ctypes.POINTER(_U64), ctypes.POINTER(_I32),
+                               ctypes.POINTER(_I32)]),
     "fwa_comm_unique_id": (_I32, [ctypes.c_char_p]),
     "fwa_comm_create": (_I32, [_P, ctypes.c_char_p, _I32, _I32, _PP]),
     "fwa_comm_destroy": (_I32, [_P]),

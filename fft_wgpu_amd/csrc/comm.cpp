@@ -4,7 +4,7 @@
 // cross-transform access).  This file only serves callers whose batch starts -- or must end up -- on one
 // GPU while the other GPUs belong to OTHER processes (one process per GPU, the deployment north_star names): root
 // scatters slabs with grouped ncclSend / ncclRecv, the mirror gathers.  One process that drives several devices itself
-// needs none of it: it holds every pointer and moves slabs with fwa_buf_copy (peer copies, api.cpp).
+// needs none of it: it holds every pointer and moves slabs with fwa_buf_copy (peer copies, buffers.cpp).
 //
 // librccl is loaded on the first fwa_comm_* call (dlopen), not linked: a caller that never shards pays neither its load time
 // nor its dependency.
@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "internal.h"
 
@@ -194,68 +195,89 @@ int32_t fwa_comm_sendrecv(fwa_comm *comm, const fwa_buf *send, uint64_t send_off
 }
 
 // Slabs follow fwa_slab(batch, rank, world): rank r owns transforms [first_r, first_r + count_r).
-int32_t fwa_comm_scatter(fwa_comm *comm, int32_t root, const fwa_buf *full_or_null, fwa_buf *slab, uint32_t fft_len,
-                         uint64_t batch, fwa_stream *stream)
+//
+// The point-to-point pieces one rank posts in a scatter or a gather -- pure host logic (no device, no RCCL), so that the
+// table both collectives are built on can be checked for every world size without a second GPU.  A rank other than the
+// root posts ONE piece (its whole slab, peer = root, offset 0 into its slab buffer); the root posts `world` pieces, piece
+// p = rank p's slab at byte offset first_p * 8 * fft_len of the full batch, peer = p, and peer = -1 for its own slab
+// (moved by a device copy on the same stream instead).
+int32_t fwa_comm_pieces(uint64_t batch, uint32_t fft_len, int32_t root, int32_t rank, int32_t world, uint64_t *offset,
+                        uint64_t *bytes, int32_t *peer, int32_t *n_pieces)
 {
-    if (!comm || !slab || !fft_len) return fwa_int::fail(comm ? comm->ctx : nullptr, FWA_ERR_INVALID_ARG, "comm/slab is NULL or fft_len is 0");
+    if (!offset || !bytes || !peer || !n_pieces) return fwa_int::fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    *n_pieces = 0;
+    if (!fft_len) return fwa_int::fail(nullptr, FWA_ERR_INVALID_ARG, "fft_len is 0");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return fwa_int::fail(nullptr, FWA_ERR_INVALID_ARG, "bad rank / root / world size");
+    const uint64_t tb = 8ull * fft_len;
+    uint64_t f = 0, n = 0;
+    if (rank != root) {
+        (void)fwa_slab(batch, rank, world, &f, &n);
+        offset[0] = 0; bytes[0] = n * tb; peer[0] = root;
+        *n_pieces = 1;
+        return FWA_OK;
+    }
+    for (int32_t p = 0; p < world; ++p) {
+        (void)fwa_slab(batch, p, world, &f, &n);
+        offset[p] = f * tb; bytes[p] = n * tb; peer[p] = p == root ? -1 : p;
+    }
+    *n_pieces = world;
+    return FWA_OK;
+}
+
+namespace {
+
+// scatter (gather = false): root's `full` -> every rank's `slab`; gather: the mirror image.  Host memory: two small
+// vectors per call on the root (these calls, unlike fwa_plan_exec, are not allocation-free).
+int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *slab, const fwa_buf *full, uint32_t fft_len,
+                   uint64_t batch, fwa_stream *stream)
+{
+    if (!comm || !slab || !fft_len)
+        return fwa_int::fail(comm ? comm->ctx : nullptr, FWA_ERR_INVALID_ARG, "comm/slab is NULL or fft_len is 0");
     fwa_ctx *ctx = comm->ctx;
     if (root < 0 || root >= comm->world) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root out of range");
-    if (stream && fwa_int::stream_ctx(stream) != ctx) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "the stream belongs to another context");
+    if (stream && fwa_int::stream_ctx(stream) != ctx)
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "the stream belongs to another context");
+    const bool is_root = comm->rank == root;
+    std::vector<uint64_t> off((size_t)(is_root ? comm->world : 1)), len(off.size());
+    std::vector<int32_t> peer(off.size());
+    int32_t np = 0;
+    int32_t st = fwa_comm_pieces(batch, fft_len, root, comm->rank, comm->world, off.data(), len.data(), peer.data(), &np);
+    if (st) return st;
     const uint64_t tb = 8ull * fft_len;
     uint64_t first = 0, count = 0;
     (void)fwa_slab(batch, comm->rank, comm->world, &first, &count);
-    if (!in_range(slab, 0, count * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "slab buffer is smaller than this rank's slab");
-    if (comm->rank != root) {
-        const Piece r{at(slab, 0), count * tb, root};
-        return exchange(comm, nullptr, 0, &r, 1, stream);
+    if (!in_range(slab, 0, count * tb))
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "slab buffer is smaller than this rank's slab");
+    if (!is_root) {
+        const Piece one{at(slab, 0), len[0], peer[0]};
+        return gather ? exchange(comm, &one, 1, nullptr, 0, stream) : exchange(comm, nullptr, 0, &one, 1, stream);
     }
-    if (!full_or_null || !in_range(full_or_null, 0, batch * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root needs the full batch buffer");
-    std::string err;
-    Piece *sends = new (std::nothrow) Piece[(size_t)comm->world];
-    if (!sends) return fwa_int::fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
-    for (int32_t p = 0; p < comm->world; ++p) {
-        uint64_t f = 0, n = 0;
-        (void)fwa_slab(batch, p, comm->world, &f, &n);
-        sends[p] = Piece{at(full_or_null, f * tb), n * tb, p == root ? -1 : p};
-    }
-    int32_t st = exchange(comm, sends, (size_t)comm->world, nullptr, 0, stream);
-    delete[] sends;
+    if (!full || !in_range(full, 0, batch * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root needs the full batch buffer");
+    std::vector<Piece> pieces((size_t)np);
+    for (int32_t p = 0; p < np; ++p) pieces[(size_t)p] = Piece{at(full, off[(size_t)p]), len[(size_t)p], peer[(size_t)p]};
+    st = gather ? exchange(comm, nullptr, 0, pieces.data(), pieces.size(), stream)
+                : exchange(comm, pieces.data(), pieces.size(), nullptr, 0, stream);
     if (st) return st;
     // the root's own slab: a device copy on the same stream (skipped when the caller's slab IS that part of the batch)
-    if (count && at(slab, 0) != at(full_or_null, first * tb))
-        st = fwa_buf_copy(slab, 0, full_or_null, first * tb, count * tb, stream);
+    if (count && at(slab, 0) != at(full, first * tb))
+        st = gather ? fwa_buf_copy(const_cast<fwa_buf *>(full), first * tb, slab, 0, count * tb, stream)
+                    : fwa_buf_copy(const_cast<fwa_buf *>(slab), 0, full, first * tb, count * tb, stream);
     return st;
+}
+
+}  // namespace
+
+int32_t fwa_comm_scatter(fwa_comm *comm, int32_t root, const fwa_buf *full_or_null, fwa_buf *slab, uint32_t fft_len,
+                         uint64_t batch, fwa_stream *stream)
+{
+    return move_slabs(comm, false, root, slab, full_or_null, fft_len, batch, stream);
 }
 
 int32_t fwa_comm_gather(fwa_comm *comm, int32_t root, const fwa_buf *slab, fwa_buf *full_or_null, uint32_t fft_len,
                         uint64_t batch, fwa_stream *stream)
 {
-    if (!comm || !slab || !fft_len) return fwa_int::fail(comm ? comm->ctx : nullptr, FWA_ERR_INVALID_ARG, "comm/slab is NULL or fft_len is 0");
-    fwa_ctx *ctx = comm->ctx;
-    if (root < 0 || root >= comm->world) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root out of range");
-    if (stream && fwa_int::stream_ctx(stream) != ctx) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "the stream belongs to another context");
-    const uint64_t tb = 8ull * fft_len;
-    uint64_t first = 0, count = 0;
-    (void)fwa_slab(batch, comm->rank, comm->world, &first, &count);
-    if (!in_range(slab, 0, count * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "slab buffer is smaller than this rank's slab");
-    if (comm->rank != root) {
-        const Piece s{at(slab, 0), count * tb, root};
-        return exchange(comm, &s, 1, nullptr, 0, stream);
-    }
-    if (!full_or_null || !in_range(full_or_null, 0, batch * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root needs the full batch buffer");
-    Piece *recvs = new (std::nothrow) Piece[(size_t)comm->world];
-    if (!recvs) return fwa_int::fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
-    for (int32_t p = 0; p < comm->world; ++p) {
-        uint64_t f = 0, n = 0;
-        (void)fwa_slab(batch, p, comm->world, &f, &n);
-        recvs[p] = Piece{at(full_or_null, f * tb), n * tb, p == root ? -1 : p};
-    }
-    int32_t st = exchange(comm, nullptr, 0, recvs, (size_t)comm->world, stream);
-    delete[] recvs;
-    if (st) return st;
-    if (count && at(slab, 0) != at(full_or_null, first * tb))
-        st = fwa_buf_copy(full_or_null, first * tb, slab, 0, count * tb, stream);
-    return st;
+    return move_slabs(comm, true, root, slab, full_or_null, fft_len, batch, stream);
 }
 
 }  // extern "C"

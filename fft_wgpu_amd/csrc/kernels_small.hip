@@ -111,7 +111,7 @@ hipError_t launch_fill(v2f *dst, uint64_t seed, uint64_t g0, uint64_t n_samples,
 }
 
 // A kernel that occupies `blocks` one-wave workgroups for `ticks` x 10 ns and touches no memory: used once per context
-// to check that the internal chain streams of the pipelined paths really run kernels side by side (api.cpp: chain_streams).
+// to check that the internal chain streams of the pipelined paths really run kernels side by side (ctx_streams.cpp: chain_streams).
 __global__ __launch_bounds__(64) void k_spin(uint32_t ticks)
 {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz

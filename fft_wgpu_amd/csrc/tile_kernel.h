@@ -11,8 +11,10 @@ __global__ __launch_bounds__(((1 << LGL) / 16) * CW) void k_tile(TileArgs a)
     constexpr int AOUT = (ROLE == ROLE_FIRST || ROLE == ROLE_MIDDLE) ? AUX_SC1 : (ROLE == ROLE_LAST ? AUX_NT : AUX_DEFAULT);
     constexpr int AIN = (ROLE == ROLE_FIRST) ? AUX_NT : AUX_DEFAULT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // XCD-aware block -> tile mapping: each XCD gets a contiguous run of tiles (see kernels_1m.hip xcd_block)
-    const uint32_t bid = a.xcd_swizzle ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // XCD-aware block -> tile mapping, bit 0 only: each XCD gets a contiguous run of tiles (xcd_map, device_common.h).  Bit 2
+    // (adjacent tiles for the two residents of a CU) means nothing for these small workgroups and is ignored, as the
+    // header's description of "xcd_swizzle" says: values without bit 0 leave every kernel of the plan unswizzled.
+    const uint32_t bid = xcd_map(a.xcd_swizzle & 1u);
     const uint32_t tile = bid % a.tile_count;
     const uint32_t rest = bid / a.tile_count;
     const uint32_t d1 = rest % a.d1_count;

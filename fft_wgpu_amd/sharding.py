@@ -154,16 +154,29 @@ class ShardedBatch:
     them from / to host memory, every device taking only its own slab.
 
     ``ordinals`` defaults to every visible device; an ordinal may repeat (two contexts on one device: the degenerate form
-    the one-GPU tests use)."""
+    the one-GPU tests use).  ``devices``: use these Device objects instead of creating one per ordinal -- the caller
+    keeps them (``destroy()`` then leaves them alone; devices created here are destroyed there).
 
-    def __init__(self, plan_cls, fft_len, batch, ordinals=None, lab=False):
+    ``proc()`` enqueues the shards from one host thread per shard when an exec is many launches (a C3-sized slab is 512
+    launches + 512 event operations = about 3 ms of host time per device against 21 ms of GPU work: serially, eight
+    devices would be host-bound; profiles/round5/enqueue_cost.jsonl); ctypes releases the GIL during the call.
+    ``threads``: None = by launch count, True / False = always / never."""
+
+    THREAD_MIN_LAUNCHES = 16   # below this an exec returns in < 0.1 ms and a thread hand-off costs as much
+
+    def __init__(self, plan_cls, fft_len, batch, ordinals=None, lab=False, devices=None, threads=None):
         from .device import Device, Queue, device_count
-        if ordinals is None:
+        if devices is not None:
+            ordinals = [d.ordinal for d in devices]
+        elif ordinals is None:
             ordinals = list(range(device_count()))
         if not ordinals:
             raise _ffi.FwaError(5, "no device visible", "ShardedBatch")
         self.fft_len, self.batch = fft_len, batch
-        self.devices = [Device(o, lab=lab) for o in ordinals]
+        self._owns_devices = devices is None
+        self.threads = threads
+        self._pool = None
+        self.devices = list(devices) if devices is not None else [Device(o, lab=lab) for o in ordinals]
         self.queues = [Queue(d) for d in self.devices]
         self.encoders = [d.create_command_encoder() for d in self.devices]
         world = len(ordinals)
@@ -181,9 +194,23 @@ class ShardedBatch:
     def __len__(self):
         return len(self.devices)
 
+    def _threaded(self):
+        if self.threads is not None:
+            return bool(self.threads) and len(self.plans) > 1
+        return len(self.plans) > 1 and max(p.get("launches_per_exec") for p in self.plans) >= self.THREAD_MIN_LAUNCHES
+
     def proc(self):
-        """Enqueue the transform of every slab on its device's encoder; returns the list of result buffers."""
-        self.results = [p.proc(e) for p, e in zip(self.plans, self.encoders)]
+        """Enqueue the transform of every slab on its device's encoder; returns the list of result buffers.  Returns when
+        every shard's launches are queued (not when they have run): with one enqueueing thread per shard that is the
+        host time of ONE shard, not their sum."""
+        if self._threaded():
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=len(self.plans), thread_name_prefix="fwa-shard")
+            futures = [self._pool.submit(p.proc, e) for p, e in zip(self.plans, self.encoders)]
+            self.results = [f.result() for f in futures]      # re-raises a shard's FwaError here
+        else:
+            self.results = [p.proc(e) for p, e in zip(self.plans, self.encoders)]
         return self.results
 
     def poll(self):
@@ -233,5 +260,13 @@ class ShardedBatch:
                 b.destroy()
         for e in self.encoders:
             e.destroy()
-        # the contexts stay (as every Device of this package does until the process ends): buffers the caller made on
-        # `devices[i]` may outlive this object
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        # contexts this object created go last (each holds its pooled ring slab, twiddle tables and chain streams until then);
+        # buffer and stream handles a caller still holds on them stay destroyable (include/fft_wgpu_amd.h, "Lifetimes").
+        # Devices the caller passed in are the caller's.
+        if self._owns_devices:
+            for d in self.devices:
+                d.destroy()
+        self.plans, self.buffers, self.seconds, self.encoders, self.results = [], [], None, [], []

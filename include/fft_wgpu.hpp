@@ -8,10 +8,12 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -209,6 +211,13 @@ public:
         new (&other_) Buffer(d_, res);  // plan-owned partner (Forward/Inverse, odd log2 n): borrowed view
         return other_;
     }
+    // fwa_plan_get_i64 ("launches_per_exec", "path", "group", ...)
+    int64_t get(const char *key) const
+    {
+        int64_t v = 0;
+        d_.check(fwa_plan_get_i64(h_, key, &v), "fwa_plan_get_i64");
+        return v;
+    }
     const uint32_t fft_len;
 
 private:
@@ -332,10 +341,34 @@ public:
     CommandEncoder &encoder(size_t i) { return *enc_[i]; }
     Buffer &buffer(size_t i) { return *buf_[i]; }      // shard i's slab (input of the transform)
     Buffer &result(size_t i) { return *result_[i]; }   // where shard i's output is after proc() (processor.rs:153-157)
-    // enqueue the transform of every slab on its device; returns without waiting
+    // Enqueue the transform of every slab on its device; returns when every shard's launches are QUEUED, without waiting
+    // for them to run.  A C3-sized slab is 512 kernel launches + 512 event operations = about 3 ms of host time per device
+    // against 21 ms of GPU work (profiles/round5/enqueue_cost.jsonl): eight devices enqueued one after another would be
+    // host-bound, so shards whose exec is many launches are enqueued from one thread per shard (every entry point makes its
+    // context's device current on the calling thread; plans of different contexts share nothing).  Link with -pthread.
+    enum class Enqueue { automatic, serial, threaded };
+    void set_enqueue(Enqueue e) { enqueue_ = e; }
+    static constexpr int64_t thread_min_launches = 16;  // below this an exec returns in < 0.1 ms: a thread costs as much
     void proc()
     {
-        for (size_t i = 0; i < dev_.size(); ++i) result_[i] = &plan_[i]->proc(*enc_[i]);
+        const size_t n = dev_.size();
+        bool threaded = enqueue_ == Enqueue::threaded;
+        if (enqueue_ == Enqueue::automatic)
+            for (size_t i = 0; i < n && !threaded; ++i) threaded = plan_[i]->get("launches_per_exec") >= thread_min_launches;
+        if (n < 2 || !threaded) {
+            for (size_t i = 0; i < n; ++i) result_[i] = &plan_[i]->proc(*enc_[i]);
+            return;
+        }
+        std::vector<std::exception_ptr> err(n);
+        auto one = [&](size_t i) {
+            try { result_[i] = &plan_[i]->proc(*enc_[i]); } catch (...) { err[i] = std::current_exception(); }
+        };
+        std::vector<std::thread> workers;
+        for (size_t i = 1; i < n; ++i) workers.emplace_back(one, i);
+        one(0);
+        for (std::thread &t : workers) t.join();
+        for (const std::exception_ptr &e : err)
+            if (e) std::rethrow_exception(e);
     }
     void synchronize()
     {
@@ -376,6 +409,7 @@ private:
     std::vector<std::unique_ptr<Buffer>> buf_, second_;
     std::vector<std::unique_ptr<PlanT>> plan_;
     std::vector<Buffer *> result_;
+    Enqueue enqueue_ = Enqueue::automatic;
 };
 
 // One rank of a slab communicator over RCCL (fwa_comm_*), for hosts that run ONE PROCESS PER GPU and do not hold each other's

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FWA_ABI_VERSION 3
+#define FWA_ABI_VERSION 4
 
 typedef enum fwa_status {
     FWA_OK = 0,
@@ -108,7 +108,8 @@ int32_t fwa_ctx_device_info(const fwa_ctx *ctx, char *name, size_t name_cap,
  *               (examples/basic.rs:76,92,105-106) ------------------------- */
 int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out);
 /* Wrap an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the null stream.
- * The wrapped stream is not destroyed by fwa_stream_destroy. */
+ * The wrapped stream is not destroyed by fwa_stream_destroy and must OUTLIVE its wrapper: the library queries wrapped
+ * handles (capture status before it creates streams of its own) and HIP does not validate stream handles. */
 int32_t fwa_stream_wrap(fwa_ctx *ctx, void *hip_stream, fwa_stream **out);
 int32_t fwa_stream_synchronize(fwa_stream *stream);
 int32_t fwa_stream_destroy(fwa_stream *stream);
@@ -236,10 +237,22 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
  *   scatter: root's `full` (batch transforms) -> every rank's `slab` (>= its count transforms); `full` is ignored elsewhere
  *   gather : every rank's `slab` -> root's `full`
  * fwa_comm_sendrecv: the primitive under both -- one send and/or one receive in one group (rank < 0 = none); sending to the
- * own rank needs the matching receive in the same call (a ring shift of slabs is `sendrecv(to = r+1, from = r-1)`). */
+ * own rank needs the matching receive in the same call (a ring shift of slabs is `sendrecv(to = r+1, from = r-1)`).
+ * Errors in a collective are fatal for the COMMUNICATOR: a rank whose arguments are rejected (FWA_ERR_INVALID_ARG: slab
+ * buffer too small, root without a full buffer, foreign stream) has posted nothing, while its peers have already enqueued
+ * the matching sends / receives and will wait on their streams for ever -- there is no timeout.  Validate sizes before
+ * the call on every rank; after a failure destroy the communicator on every rank (and the processes with it, if peers
+ * are already blocked).  These calls allocate a few small host vectors on the root; fwa_plan_exec never allocates.
+ * fwa_comm_pieces: pure host logic, no device and no RCCL needed -- the point-to-point pieces rank `rank` posts in a
+ * scatter or gather of `batch` transforms rooted at `root` (the table both collectives are built on; arrays of `world`
+ * entries): a non-root rank posts one piece (offset 0 into its slab buffer, its whole slab, peer = root), the root posts
+ * `world` pieces (byte offset of rank p's slab in the full batch, its bytes, peer = p, or -1 for the root's own slab,
+ * which moves by a device copy on the same stream). */
 typedef struct fwa_comm fwa_comm;
 #define FWA_COMM_ID_BYTES 128
 int32_t fwa_slab(uint64_t batch, int32_t rank, int32_t world, uint64_t *first, uint64_t *count);
+int32_t fwa_comm_pieces(uint64_t batch, uint32_t fft_len, int32_t root, int32_t rank, int32_t world, uint64_t *offset,
+                        uint64_t *bytes, int32_t *peer, int32_t *n_pieces);
 int32_t fwa_comm_unique_id(uint8_t id[FWA_COMM_ID_BYTES]);
 int32_t fwa_comm_create(fwa_ctx *ctx, const uint8_t id[FWA_COMM_ID_BYTES], int32_t world, int32_t rank, fwa_comm **out);
 int32_t fwa_comm_destroy(fwa_comm *comm);

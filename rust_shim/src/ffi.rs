@@ -58,6 +58,7 @@ extern "C" {
     pub fn fwa_plan_get_i64(plan: *const fwa_plan, key: *const c_char, value: *mut i64) -> i32;
     pub fn fwa_plan_set_i64(plan: *mut fwa_plan, key: *const c_char, value: i64) -> i32;
     pub fn fwa_slab(batch: u64, rank: i32, world: i32, first: *mut u64, count: *mut u64) -> i32;
+    pub fn fwa_comm_pieces(batch: u64, fft_len: u32, root: i32, rank: i32, world: i32, offset: *mut u64, bytes: *mut u64, peer: *mut i32, n_pieces: *mut i32) -> i32;
     pub fn fwa_comm_unique_id(id: *mut u8) -> i32;
     pub fn fwa_comm_create(ctx: *mut fwa_ctx, id: *const u8, world: i32, rank: i32, out: *mut *mut fwa_comm) -> i32;
     pub fn fwa_comm_destroy(comm: *mut fwa_comm) -> i32;

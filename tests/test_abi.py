@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     # and the ctypes table covers the header exactly
     assert sorted(_ffi._SIGNATURES) == names
-    assert L.fwa_abi_version() == 3
+    assert L.fwa_abi_version() == 4
 
 
 def test_laboratory_library_has_the_same_abi_and_the_product_has_no_laboratory_kernels():
@@ -164,7 +164,7 @@ def test_cpp_mirror_compiles_against_the_header(tmp_path):
     exe = tmp_path / "example"
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tools", "example_basic_inverse2.cpp"),
-                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-pthread", "-o", str(exe)])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True)
     if torch.cuda.is_available():

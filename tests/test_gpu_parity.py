@@ -261,25 +261,65 @@ def test_n1m_matches_literal_recurrence(gpu, oracle):
 
 
 # ---- distance to the fp32 restatement of the reference (oracle/ref_fft.c), all three transforming plans ----
-@pytest.mark.parametrize("n,batch", [(512, 20), (1 << 20, 4)])
-def test_distance_to_reference_restatement(gpu, oracle, n, batch):
+# One case per BASELINE.json config shape that fits the CPU restatement in seconds and per kernel family (VERDICT round 4,
+# item 3): what each case runs is asserted through the plan's path / factors / launch count below.
+_DISTANCE_CASES = [
+    # (n, batch, expected (path, factors, launches per exec), kernels)
+    (256, 40, (0, None, 1), "k_chunk"),
+    (512, 20, (0, None, 1), "k_small32<9> (the reference's own length, examples/basic.rs:32)"),
+    (1024, 1, (0, None, 1), "k_small32<10>: config C1's shape"),
+    (1 << 13, 6, (0, None, 1), "k_small32<13>: two exchanges"),
+    (1 << 15, 3, (0, None, 1), "k_small32<15>: 1024 threads"),
+    (1 << 16, 2, (7, 8 | 8 << 8, 2), "latency regime: k_tile columns + k_tile rows (256 x 256)"),
+    (1 << 17, 9, (7, 8 | 9 << 8, 2), "k_colsw<8,64> + k_rows32<9>"),
+    (1 << 20, 1, (7, 6 | 6 << 8 | 8 << 16, 3), "config C2: three balanced k_tile passes"),
+    (1 << 20, 4, (1, 10 | 10 << 8, 2), "k_p1_1m + k_p2_1m: config C3's pipeline"),
+    (1 << 22, 2, (7, 10 | 12 << 8, 2), "k_p1_gen + k_rows32<12>"),
+    (1 << 23, 1, (7, 11 | 12 << 8, 2), "k_cols32<11> + k_rows32<12>"),
+    (1 << 24, 1, (7, 9 | 7 << 8 | 8 << 16, 3), "config C5: k_colsw<9,32> + k_tile columns + k_tile rows"),
+]
+
+
+@pytest.mark.parametrize("n,batch,shape,kernels", _DISTANCE_CASES, ids=["%dx%d" % (c[0], c[1]) for c in _DISTANCE_CASES])
+def test_distance_to_reference_restatement(gpu, oracle, n, batch, shape, kernels):
     """HIP result vs the CPU restatement of the reference's own arithmetic -- forward: table twiddles
-    (processor.rs:43-49, fft.wgsl:27-62); inverse: on-the-fly f32 cos/sin twiddles and the fused 1/n of the
-    last stage (ifft.wgsl:41-42,65-74); Onlyinverse: the same without the scale (onlyifft.wgsl:25-64).
-    Bound: the north-star 1e-5 (max-abs error / max-abs reference, per transform)."""
+    (processor.rs:43-49, fft.wgsl:27-62); inverse: on-the-fly f32 cos/sin twiddles per butterfly and the fused 1/n of
+    the last stage (ifft.wgsl:41-42,65-74) where this library uses conjugated f64-derived tables; Onlyinverse: the same
+    without the scale (onlyifft.wgsl:25-64).  Bound: the north-star 1e-5 (max-abs error / max-abs reference, per
+    transform), at every config shape and for every kernel family.  With FWA_DISTANCE_TABLE=<file> every case appends
+    its numbers (BASELINE.md's table), the restatement's own distance to the fp64 DFT beside them."""
+    import json
     fw, dev, queue = gpu
     x = oracle.gen_input(n, batch, first_transform=3)
-    for kind, ref in (("Forward", oracle.forward_ref), ("Inverse", oracle.inverse_ref),
-                      ("Onlyinverse", oracle.onlyinverse_ref)):
-        y, which, _ = _run(fw, dev, queue, kind, x, n)
+    rows = []
+    for kind, ref, direction in (("Forward", oracle.forward_ref, -1), ("Inverse", oracle.inverse_ref, 1),
+                                 ("Onlyinverse", oracle.onlyinverse_ref, 1)):
+        y, which, plan = _run(fw, dev, queue, kind, x, n)
+        path, factors, launches = shape
+        assert plan.get("path") == path and plan.get("launches_per_exec") == launches, (plan.get("path"), plan.get("launches_per_exec"))
+        if factors is not None:
+            assert plan.get("factors") == factors, hex(plan.get("factors"))
         yr, which_ref = ref(x, n)
         assert which == which_ref == int(np.log2(n)) % 2   # processor.rs:153-157
-        worst = 0.0
+        exact = oracle.dft_f64(x, n, direction)
+        if kind == "Inverse":
+            exact = exact / n
+        worst = ours = theirs = 0.0
         for t in range(batch):
             a, r = y[t * n:(t + 1) * n].astype(np.complex128), yr[t * n:(t + 1) * n].astype(np.complex128)
+            e = exact[t * n:(t + 1) * n]
             worst = max(worst, np.abs(a - r).max() / np.abs(r).max())
+            ours = max(ours, np.abs(a - e).max() / np.abs(e).max())
+            theirs = max(theirs, np.abs(r - e).max() / np.abs(e).max())
         assert worst <= REL_TOL, (kind, n, worst)
-        print("%s n=%d: max distance to the fp32 restatement of the reference %.3g" % (kind, n, worst))
+        print("%s n=%d x %d [%s]: max distance to the fp32 restatement of the reference %.3g (to the fp64 DFT: HIP %.3g, restatement %.3g)"
+              % (kind, n, batch, kernels, worst, ours, theirs))
+        rows.append({"n": n, "batch": batch, "plan": kind, "kernels": kernels, "hip_vs_restatement": worst,
+                     "hip_vs_dft_f64": ours, "restatement_vs_dft_f64": theirs})
+    if os.environ.get("FWA_DISTANCE_TABLE"):
+        with open(os.environ["FWA_DISTANCE_TABLE"], "a") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
 
 
 # ---- tiled path: several groups, two chains, ragged last group, 16- and 32-wide tiles ----
@@ -735,7 +775,7 @@ def test_cpp_mirror_replays_reference_example(gpu, tmp_path, example):
     exe = tmp_path / "example"
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tools", example + ".cpp"),
-                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-pthread", "-o", str(exe)])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
@@ -752,7 +792,7 @@ def test_cpp_host_pipeline_replays_reference_benchmark_loop(gpu, tmp_path):
     exe = tmp_path / "example_basic_pipeline"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tools", "example_basic_pipeline.cpp"),
-                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-pthread", "-o", str(exe)])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe), "200", "3"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)

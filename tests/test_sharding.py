@@ -55,7 +55,7 @@ def test_c_abi_and_cpp_slab_rule_for_world_1_to_8(tmp_path):
                    '  return 0; }\n')
     exe = tmp_path / "slabs"
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), str(src),
-                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-o", str(exe)])
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-pthread", "-o", str(exe)])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fft_wgpu_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)] + [str(b) for b in batches], env=env, capture_output=True, text=True, check=True).stdout.split("\n")
     cpp = {}
@@ -206,3 +206,42 @@ def test_bench_launcher_stops_the_other_ranks_when_one_dies():
     assert bench.supervise([subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]) == 0
     killed = subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"])
     assert bench.supervise([killed], log=io.StringIO()) == 128 + 9
+
+
+def test_scatter_gather_piece_tables_for_world_2_to_8():
+    """the per-peer tables fwa_comm_scatter / fwa_comm_gather post (fwa_comm_pieces: pure host logic, the
+    function both collectives build their grouped sends / receives from) for every world size 1..8, every root, ragged
+    and empty batches: the root's pieces tile the full batch in rank order with peer = rank and -1 for its own slab; every
+    other rank posts exactly one piece, its slab, to / from the root.  What stays untested without a second GPU is the
+    RCCL call itself."""
+    import ctypes
+    from fft_wgpu_amd import _ffi
+    from fft_wgpu_amd.sharding import slab
+    L = _ffi.lib()
+    for n in (512, 1 << 20):
+        tb = 8 * n
+        for world in range(1, 9):
+            off, nb, peer = (ctypes.c_uint64 * world)(), (ctypes.c_uint64 * world)(), (ctypes.c_int32 * world)()
+            cnt = ctypes.c_int32()
+            for batch in (0, 1, world - 1, world, 3 * world + 2, 4096 * world, (1 << 33) + 5):
+                for root in range(world):
+                    for rank in range(world):
+                        assert L.fwa_comm_pieces(batch, n, root, rank, world, off, nb, peer, ctypes.byref(cnt)) == 0
+                        lo, hi = slab(batch, rank, world)
+                        if rank != root:
+                            assert cnt.value == 1 and (off[0], nb[0], peer[0]) == (0, (hi - lo) * tb, root)
+                            continue
+                        assert cnt.value == world
+                        nxt = 0
+                        for p in range(world):
+                            a, b = slab(batch, p, world)
+                            assert (off[p], nb[p]) == (a * tb, (b - a) * tb) and off[p] == nxt
+                            assert peer[p] == (-1 if p == root else p)
+                            nxt += nb[p]
+                        assert nxt == batch * tb
+    cnt = ctypes.c_int32(9)
+    one = (ctypes.c_uint64 * 1)()
+    pr = (ctypes.c_int32 * 1)()
+    assert L.fwa_comm_pieces(8, 512, 2, 0, 2, one, one, pr, ctypes.byref(cnt)) == 1 and cnt.value == 0   # root out of range
+    assert L.fwa_comm_pieces(8, 0, 0, 0, 1, one, one, pr, ctypes.byref(cnt)) == 1                       # fft_len 0
+    assert L.fwa_comm_pieces(8, 512, 0, 0, 1, None, one, pr, ctypes.byref(cnt)) == 1

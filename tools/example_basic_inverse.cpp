@@ -2,7 +2,7 @@
 // include/fft_wgpu.hpp: Inverse (1/n fused), n = 512, 1.28 M samples of 2 + 42i (:160), result copied to a staging buffer
 // and read back (:184-205); expected: the constant at bin 0 of every transform, 0 elsewhere, max |error| < 1e-5 (:238-253 --
 // the reference compares with rustfft's inverse / 512, which is exactly that for a constant input).
-// Build: g++ -std=c++17 -Iinclude tools/example_basic_inverse.cpp -Lfft_wgpu_amd -lfft_wgpu_amd
+// Build: g++ -std=c++17 -Iinclude tools/example_basic_inverse.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -pthread
 #include <cmath>
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,5 @@
 // C++ replay of reference src/examples/basic_inverse2.rs (main :3-137 and test_ifft :139-286) through
-// include/fft_wgpu.hpp.  Build: g++ -std=c++17 -Iinclude tools/example_basic_inverse2.cpp -Lfft_wgpu_amd -lfft_wgpu_amd
+// include/fft_wgpu.hpp.  Build: g++ -std=c++17 -Iinclude tools/example_basic_inverse2.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -pthread
 #include <cmath>
 #include <cstdio>
 #include <new>

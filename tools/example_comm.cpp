@@ -3,7 +3,7 @@
 //   example_comm [log2_fft_len] [batch]          world / rank / device from WORLD_SIZE / RANK / LOCAL_RANK (default 1 / 0 / 0);
 //                                                the communicator id travels through the file $FWA_COMM_ID_FILE (rank 0 writes it)
 // On a one-GPU box only the world of one rank can run (RCCL refuses two ranks on one device): that is what the tests start.
-// Build: g++ -std=c++17 -Iinclude tools/example_comm.cpp -Lfft_wgpu_amd -lfft_wgpu_amd
+// Build: g++ -std=c++17 -Iinclude tools/example_comm.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -pthread
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>

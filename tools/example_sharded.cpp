@@ -2,10 +2,11 @@
 // bit for bit against the unsharded transform of the same samples on device 0.
 //   example_sharded [log2_fft_len] [batch] [shards]      shards = 0: one per visible device; an ordinal repeats when
 //                                                        shards exceeds the device count (two contexts on one GPU)
-// Three legs: (1) host -> slabs -> proc -> host; (2) the batch starts on device 0: scatter (peer copies) -> proc -> gather;
+// Legs: (1) host -> slabs -> proc -> host; (2) the batch starts on device 0: scatter (peer copies) -> proc -> gather;
+// (2b) proc() enqueued from one thread per shard and serially;
 // (3) Onlyinverse + Normalize shards (caller-supplied second buffers) undo leg 1.  Exit 0 = all identical, 1 = mismatch,
 // 2 = library error (no device: "error 5").
-// Build: g++ -std=c++17 -Iinclude tools/example_sharded.cpp -Lfft_wgpu_amd -lfft_wgpu_amd
+// Build: g++ -std=c++17 -Iinclude tools/example_sharded.cpp -Lfft_wgpu_amd -lfft_wgpu_amd -pthread
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,17 @@ int main(int argc, char **argv)
         std::memset(y.data(), 0, bytes);
         if (bytes) back.read(y.data(), bytes, &e0);
         if (bytes && std::memcmp(y.data(), ref.data(), bytes) != 0) { std::fprintf(stderr, "leg 2: scatter/proc/gather != unsharded\n"); return 1; }
+
+        // leg 2b: both enqueue forms of proc() -- one host thread per shard, and one after another -- give the same bits
+        for (auto mode : {ShardedBatch<Forward>::Enqueue::threaded, ShardedBatch<Forward>::Enqueue::serial}) {
+            sb.set_enqueue(mode);
+            sb.write(x.data());
+            sb.proc();
+            std::memset(y.data(), 0, bytes);
+            sb.read(y.data());
+            if (bytes && std::memcmp(y.data(), ref.data(), bytes) != 0) { std::fprintf(stderr, "leg 2b: enqueue mode %d != unsharded\n", (int)mode); return 1; }
+        }
+        sb.set_enqueue(ShardedBatch<Forward>::Enqueue::automatic);
 
         // leg 3: Onlyinverse then Normalize per shard brings the samples back (<= 1e-5 relative, the reference's bound)
         ShardedBatch<Onlyinverse> inv(n, batch, ordinals);
