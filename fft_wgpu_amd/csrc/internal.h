@@ -129,7 +129,8 @@ struct fwa_plan {
     int64_t tile_ring = 1;         // k_colsw + k_rows32: 1 = tile-contiguous ring slab, 0 = matrix layout
     int64_t ring_rotate = 1;       // laboratory: the ring is this many times larger and the groups rotate through it (same
                                    // launches, larger cache footprint: prices what the Infinity Cache gives the ring)
-    int64_t wave = 0;              // n = 512: 1 = k_wave512 (wave-private, linear 512-byte accesses), 0 = k_small32<9>
+    int64_t wave = 1;              // n = 512: 1 = k_wave512 (wave-private, a wave's four transforms one at a time: 0.78 of the
+                                   // roofline against 0.71, profiles/round5/ab_wave512.jsonl), 0 = k_small32<9>
     int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;

@@ -42,7 +42,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         }
     }
     else if (k == "small_reg") *value = plan->small_reg;
-    else if (k == "wave") *value = plan->wave;
+    else if (k == "wave") *value = (plan->path == PATH_SMALL && plan->n == 512) ? plan->wave : 0;
     else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "rows32") *value = plan->rows32;
     else if (k == "colsw") *value = plan->colsw;

@@ -266,7 +266,7 @@ def test_n1m_matches_literal_recurrence(gpu, oracle):
 _DISTANCE_CASES = [
     # (n, batch, expected (path, factors, launches per exec), kernels)
     (256, 40, (0, None, 1), "k_chunk"),
-    (512, 20, (0, None, 1), "k_small32<9> (the reference's own length, examples/basic.rs:32)"),
+    (512, 20, (0, None, 1), "k_wave512 (the reference's own length, examples/basic.rs:32)"),
     (1024, 1, (0, None, 1), "k_small32<10>: config C1's shape"),
     (1 << 13, 6, (0, None, 1), "k_small32<13>: two exchanges"),
     (1 << 15, 3, (0, None, 1), "k_small32<15>: 1024 threads"),
@@ -541,6 +541,35 @@ def test_onlyinverse_plus_normalize_equals_inverse(gpu, oracle):
         y2 = out.map_read(stream=enc)
         y1, _, _ = _run(fw, dev, queue, "Inverse", x, n)
         assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))             # K6, bit for bit
+
+
+@pytest.mark.parametrize("batch", [1, 3, 4, 15, 16, 17, 61, 4099])
+def test_n512_wave_private_kernel_and_its_alternative(gpu, oracle, batch):
+    """n = 512, the reference's own length (examples/basic.rs:32,66): the default kernel k_wave512 (every wave walks 16 KiB =
+    four transforms and takes them one at a time: wave_kernel.h) and the alternative k_small32<9> ("wave" = 0), all three
+    transforming plans, against the fp64 DFT; batches that leave a wave (4 transforms), a workgroup (16) and the last chunk
+    ragged; the result lands in the second buffer (odd log2 n, processor.rs:153-157); the two kernels agree to rounding."""
+    fw, dev, queue = gpu
+    n = 512
+    x = oracle.gen_input(n, batch, first_transform=batch)
+    for kind, direction in (("Forward", -1), ("Inverse", 1), ("Onlyinverse", 1)):
+        r = oracle.dft_f64(x, n, direction)
+        if kind == "Inverse":
+            r = r / n
+        got = {}
+        for wave in (1, 0):
+            y, which, plan = _run(fw, dev, queue, kind, x, n, wave=wave)
+            assert which == 1 and plan.get("wave") == wave and plan.get("path") == 0 and plan.get("launches_per_exec") == 1
+            _check(oracle, y, r, n)
+            got[wave] = y
+        d = np.abs(got[1].astype(np.complex128) - got[0]).max() / np.abs(r).max()
+        assert d <= 2e-6, (kind, d)
+    # the key exists for n = 512 only
+    src = _upload(fw, dev, queue, oracle.gen_input(1024, 2))
+    p = fw.Forward(dev, queue, src, 1024)
+    with pytest.raises(fw.FwaError) as e:
+        p.set("wave", 1)
+    assert e.value.status == 6 and p.get("wave") == 0
 
 
 def test_calibration_copy_is_a_copy(gpu, oracle):

@@ -1,14 +1,16 @@
-// Where does k_wave512's time go?  The library kernel (fft_wgpu_amd/csrc/wave_kernel.h) with parts knocked out -- no
-// twiddles, no LDS exchanges, no arithmetic at all -- in place and out of place, at a footprint of 2^lg samples.
-// Knocked-out variants compute nothing meaningful: timing only.
+// The n = 512 wave-private kernel: where the time of the side-by-side form goes (parts knocked out -- no twiddles, no LDS
+// exchanges, no arithmetic at all: timing only, nothing meaningful is computed) and the forms that take a wave's four
+// transforms one at a time, persistent or not (tools/wave_kernel_variants.h), beside the library kernel
+// (fft_wgpu_amd/csrc/wave_kernel.h), in place and out of place, at a footprint of 2^lg samples.
 //   wave_probe [log2_samples = 32] [rounds = 3]
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ifft_wgpu_amd/csrc tools/wave_probe.hip -o tools/wave_probe
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ifft_wgpu_amd/csrc -Itools tools/wave_probe.hip -o tools/wave_probe
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "wave_kernel.h"
+#include "wave_kernel_variants.h"
 
 using fwa::v2f;
 
@@ -23,14 +25,19 @@ __global__ void k_fill(v2f *p, uint64_t n)
 template <int KNOCK>
 static void launch(const v2f *src, v2f *dst, const v2f *tw, uint64_t n_samples, hipStream_t st)
 {
-    hipLaunchKernelGGL((fwa::k_wave512<fwa::FWD, KNOCK>), dim3((uint32_t)(n_samples / 8192)), dim3(256), 0, st, src, dst, tw, n_samples, 1.0f);
+    hipLaunchKernelGGL((fwa_probe::k_wave512<fwa::FWD, KNOCK>), dim3((uint32_t)(n_samples / 8192)), dim3(256), 0, st, src, dst, tw, n_samples, 1.0f);
+}
+
+static void launch_lib(const v2f *src, v2f *dst, const v2f *tw, uint64_t n_samples, hipStream_t st)
+{
+    hipLaunchKernelGGL((fwa::k_wave512<fwa::FWD>), dim3((uint32_t)(n_samples / 8192)), dim3(256), 0, st, src, dst, tw, n_samples, 1.0f);
 }
 
 template <bool PERSIST, int GRID>
 static void launch_s(const v2f *src, v2f *dst, const v2f *tw, uint64_t n_samples, hipStream_t st)
 {
     const uint32_t chunks = (uint32_t)(n_samples / 8192);
-    hipLaunchKernelGGL((fwa::k_wave512s<fwa::FWD, PERSIST, 0>), dim3(PERSIST ? (GRID < (int)chunks ? GRID : chunks) : chunks), dim3(256), 0, st, src, dst, tw,
+    hipLaunchKernelGGL((fwa_probe::k_wave512s<fwa::FWD, PERSIST, 0>), dim3(PERSIST ? (GRID < (int)chunks ? GRID : chunks) : chunks), dim3(256), 0, st, src, dst, tw,
                        n_samples, 1.0f);
 }
 
@@ -55,7 +62,8 @@ int main(int argc, char **argv)
     const V vs[] = {{"full", launch<0>}, {"no_twiddles", launch<1>}, {"no_exchanges", launch<2>}, {"no_twiddles_no_exchanges", launch<3>},
                     {"loads_and_stores_only", launch<4 | 2>}, {"serial_transforms", launch_s<false, 0>},
                     {"serial_persistent_grid1024", launch_s<true, 1024>}, {"serial_persistent_grid2048", launch_s<true, 2048>},
-                    {"serial_persistent_grid4096", launch_s<true, 4096>}};
+                    {"serial_persistent_grid4096", launch_s<true, 4096>},
+                    {"library_kernel", launch_lib}};
     // the serial variants compute the same bits as the library kernel
     {
         const uint64_t ns = 1ull << 24;
@@ -64,7 +72,7 @@ int main(int argc, char **argv)
         std::vector<v2f> ref(ns), got(ns);
         CK(hipMemcpyAsync(ref.data(), b, ns * 8, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
-        for (int k = 5; k < 9; ++k) {
+        for (int k = 5; k < 10; ++k) {
             CK(hipMemsetAsync(b, 0, ns * 8, st));
             vs[k].fn(a, b, tw, ns, st);
             CK(hipMemcpyAsync(got.data(), b, ns * 8, hipMemcpyDeviceToHost, st));
@@ -75,25 +83,30 @@ int main(int argc, char **argv)
             if (bad) return 1;
         }
     }
-    for (int place = 0; place < 2; ++place)
-        for (const V &v : vs) {
-            std::vector<float> ms;
-            for (int r = 0; r < rounds * 3 + 1; ++r) {
-                hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, st, a, n_samples);
-                CK(hipEventRecord(e0, st));
-                v.fn(a, place ? b : a, tw, n_samples, st);
-                CK(hipEventRecord(e1, st));
-                CK(hipEventSynchronize(e1));
-                float t = 0;
-                CK(hipEventElapsedTime(&t, e0, e1));
-                if (r) ms.push_back(t);
-            }
-            std::sort(ms.begin(), ms.end());
-            const double med = ms[ms.size() / 2];
+    // interleaved: every round runs every variant (three launches each), so that drift of the box hits all of them alike
+    constexpr int NV = sizeof(vs) / sizeof(vs[0]);
+    for (int place = 0; place < 2; ++place) {
+        std::vector<float> ms[NV];
+        for (int r = 0; r < rounds + 1; ++r)
+            for (int k = 0; k < NV; ++k)
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, st, a, n_samples);
+                    CK(hipEventRecord(e0, st));
+                    vs[k].fn(a, place ? b : a, tw, n_samples, st);
+                    CK(hipEventRecord(e1, st));
+                    CK(hipEventSynchronize(e1));
+                    float t = 0;
+                    CK(hipEventElapsedTime(&t, e0, e1));
+                    if (r) ms[k].push_back(t);
+                }
+        for (int k = 0; k < NV; ++k) {
+            std::sort(ms[k].begin(), ms[k].end());
+            const double med = ms[k][ms[k].size() / 2];
             std::printf("{\"variant\": \"%s\", \"placement\": \"%s\", \"log2_samples\": %d, \"ms_median\": %.4f, \"ms_min\": %.4f, \"TBps\": %.3f, "
-                        "\"roofline_frac\": %.4f}\n", v.name, place ? "out_of_place" : "in_place", lg, med, ms.front(),
-                        16.0 * n_samples / (med * 1e-3) / 1e12, 16.0 * n_samples / (med * 1e-3) / 8e12);
+                        "\"roofline_frac\": %.4f, \"samples\": %zu}\n", vs[k].name, place ? "out_of_place" : "in_place", lg, med, ms[k].front(),
+                        16.0 * n_samples / (med * 1e-3) / 1e12, 16.0 * n_samples / (med * 1e-3) / 8e12, ms[k].size());
             std::fflush(stdout);
         }
+    }
     return 0;
 }
