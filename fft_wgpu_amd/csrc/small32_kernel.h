@@ -18,7 +18,17 @@ namespace fwa {
 // ---------------------------------------------------------------------------
 // The body for workgroup index `blk` (k_small32: blk = blockIdx.x; tools/small32_persist_probe.hip walks it through a
 // persistent loop, measured no faster: profiles/round3/probe_small32_persistent_negative.txt).
-template <int LGN, int DIR>
+// PREFETCH: where the twiddle-table look-ups are issued.  At the point of use (0) each costs its wave an exposed cache
+// latency between the last data load landing and the exchange; they depend on the thread index only, so they can go out
+// BEFORE the data loads (bit 0: the twiddles of stage 0, bit 1: those of stage 1 of the three-stage sizes) or right BEHIND
+// them, before the wait for the data (bits 2, 3).  Per size, at the 32-GiB footprint, interleaved, bit-identical results
+// (tools/small32_prefetch_probe.hip, profiles/round5/probe_small32_twiddle_prefetch.jsonl): 2^10 0.775 -> 0.790 (behind),
+// 2^11 0.740 -> 0.790 (both stages, before), 2^12 0.705 -> 0.738 (behind), 2^13 0.717 -> 0.739 (behind); where the extra
+// live registers spill (stage 1 at 2^12, 2^14, 2^15) or the schedule changes for the worse (2^14: - 1 ... - 9 %, 2^15:
+// - 2 ... - 4 %) the look-ups stay at the point of use.
+constexpr int small32_prefetch_default(int lgn) { return lgn == 11 ? 3 : (lgn == 10 || lgn == 12 || lgn == 13) ? 4 : 0; }
+
+template <int LGN, int DIR, int PREFETCH = small32_prefetch_default(LGN)>
 __device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *__restrict__ dst, const v2f *__restrict__ tw,
                                              uint64_t batch, float scale, uint64_t blk, uint32_t tid)
 {
@@ -63,11 +73,20 @@ __device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *_
     const uint32_t t_hi = t >> 5, t_lo = t & 31;
     const uint32_t rbase = t + t_hi;  // P(t): every read position is element t plus a constant
 
+    Twiddles<32, N> w0;
+    Twiddles<R1, N> w1[B1];
+    if constexpr (PREFETCH & 1) twiddle_fetch<32, N>(w0, tw, t);
+    if constexpr (!TWO && (PREFETCH & 2))
+        static_for<0, B1>([&](auto b_) { constexpr int b = decltype(b_)::value; twiddle_fetch<R1, N>(w1[b], tw, (t + b * T) & ~31u); });
     v2f x[32];
     // stage 0: radix 32, J = 1, s = t; output q is left in x[brev(q)] and goes to position t*32 + q (P = 33*t + q)
     static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, voff, m * T * 8); });
+    if constexpr (PREFETCH & 4) twiddle_fetch<32, N>(w0, tw, t);   // behind the data loads, before the wait for them
+    if constexpr (!TWO && (PREFETCH & 8))
+        static_for<0, B1>([&](auto b_) { constexpr int b = decltype(b_)::value; twiddle_fetch<R1, N>(w1[b], tw, (t + b * T) & ~31u); });
     fft_reg<32, DIR>(x);
-    twiddle_outputs<32, N, DIR>(x, tw, t);
+    if constexpr (PREFETCH & 5) twiddle_apply<32, N, DIR>(x, w0);
+    else twiddle_outputs<32, N, DIR>(x, tw, t);
     // -> stage 1 (radix R1, J = 32): butterfly b of this thread is idx = t + b*T, input m at idx + m*N/R1
     exchange(x, 33 * t, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, rbase, [&](auto i_) {
         constexpr uint32_t i = decltype(i_)::value;
@@ -90,7 +109,8 @@ __device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *_
             v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
             fft_reg<R1, DIR>(z);
             const uint32_t idx = t + b * T, sJ = idx & ~31u;
-            twiddle_outputs<R1, N, DIR>(z, tw, sJ);  // output q: position sJ*R1 + j + q*32
+            if constexpr (PREFETCH & 10) twiddle_apply<R1, N, DIR>(z, w1[b]);
+            else twiddle_outputs<R1, N, DIR>(z, tw, sJ);  // output q: position sJ*R1 + j + q*32
         });
         __syncthreads();  // every read of the first exchange is done before its buffer is rewritten
         // -> stage 2 (radix R2, J = N/R2, s = 0): butterfly b is idx = t + b*T < N/R2, input m at idx + m*N/R2.
@@ -116,13 +136,13 @@ __device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *_
     }
 }
 
-template <int LGN, int DIR>
+template <int LGN, int DIR, int PREFETCH = small32_prefetch_default(LGN)>
 __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_small32(const v2f *__restrict__ src,
                                                                                     v2f *__restrict__ dst,
                                                                                     const v2f *__restrict__ tw,
                                                                                     uint64_t batch, float scale)
 {
-    small32_body<LGN, DIR>(src, dst, tw, batch, scale, blockIdx.x, threadIdx.x);
+    small32_body<LGN, DIR, PREFETCH>(src, dst, tw, batch, scale, blockIdx.x, threadIdx.x);
 }
 
 static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }  // lg_n >= 6
