@@ -95,13 +95,14 @@ _libs = {}
 
 
 def lib(lab=False):
-    """Load the shared library (once).  Raises if it was not built: no CPU fallback exists."""
-    path = LAB_LIB_PATH if lab else LIB_PATH
+    """Load the shared library (once).  Raises if it was not built: no CPU fallback exists.  `lab`: False = the product,
+    True = the laboratory build, a path = that build of the same sources (tools/build_variant.sh: A/B of compile-time defaults)."""
+    path = lab if isinstance(lab, str) else (LAB_LIB_PATH if lab else LIB_PATH)
     if path not in _libs:
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                f"or `make -C fft_wgpu_amd/csrc{' lab' if lab else ''}`.  fft_wgpu_amd has no CPU fallback.")
+                f"or `make -C fft_wgpu_amd/csrc{' lab' if lab is True else ''}`.  fft_wgpu_amd has no CPU fallback.")
         L = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here = header/library mismatch

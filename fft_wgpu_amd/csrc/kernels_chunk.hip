@@ -16,6 +16,16 @@
 // writes any of it.
 #include "device_common.h"
 
+// Where the 15 stage-0 twiddle look-ups of n >= 32 (they depend on the thread index only and are the same for both halves)
+// are issued: 0 = at the point of use, once per half -- each an exposed cache latency inside the barrier-to-barrier phase;
+// 1 = once, before the data loads; 4 = once, right behind them.  Per size at the 32-GiB footprint, one library per value,
+// interleaved (tools/ab_libs.py, profiles/round5/ab_twiddle_prefetch_chunk.jsonl; identical bits): 32: 0.758 -> 0.800 (behind),
+// 64: 0.740 -> 0.785 (before), 128: 0.764 -> 0.780 (before; behind: 0.729), 256: 0.751 -> 0.777 (behind).
+#ifndef FWA_PF_CHUNK
+#define FWA_PF_CHUNK -1
+#endif
+constexpr int chunk_prefetch_default(int lgn) { return (lgn == 6 || lgn == 7) ? 1 : 4; }
+
 namespace fwa {
 
 template <int LGN, int DIR, int AIN = AUX_NT, int AOUT = AUX_NT>
@@ -42,8 +52,16 @@ __global__ __launch_bounds__(256, (LGN >= 6 ? 3 : 4)) void k_chunk(const v2f *__
     // 1024-sample blocks of a half are whole transforms, back to back
     const uint32_t park = wv * 1024 + lane;
 
+    constexpr int PF = LGN > 4 ? (FWA_PF_CHUNK < 0 ? chunk_prefetch_default(LGN) : FWA_PF_CHUNK) : 0;
+    v2f wpre[16];
+    auto prefetch = [&] {
+        if constexpr (LGN > 4)
+            static_for<1, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; wpre[q] = tw_lookup<N>(tw, (tid % (N / 16)) * q); });
+    };
+    if constexpr (PF & 1) prefetch();
     v2f y[32];
     static_for<0, 32>([&](auto i_) { constexpr int i = decltype(i_)::value; y[i] = buf_load<AIN>(rin, voff, i * 512); });
+    if constexpr (PF & 4) prefetch();
   static_for<0, 2>([&](auto h_) {
     constexpr int h = decltype(h_)::value;
     v2f x[16], v[16];
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256, (LGN >= 6 ? 3 : 4)) void k_chunk(const v2f *__
         static_for<0, 16>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             v[q] = x[brev<16>(q)];
-            if constexpr (q != 0) v[q] = cmul_tw<DIR>(v[q], tw_lookup<N>(tw, t * q));
+            if constexpr (q != 0) v[q] = cmul_tw<DIR>(v[q], (PF & 5) ? wpre[q] : tw_lookup<N>(tw, t * q));
         });
         __syncthreads();  // every stage-0 operand has been read
         static_for<0, 16>([&](auto q_) { constexpr int q = decltype(q_)::value; lds[pad(t * 16 + q)] = v[q]; });

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024, 4) void k_cols32(const v2f *__restrict__ in, 
     const uint32_t rbase = kk + k_hi;
 
     fft_reg<32, DIR>(x);
-    twiddle_outputs<32, N, DIR>(x, tw, kk);
+    twiddle_outputs<32, N, DIR>(x, tw, kk);   // look-ups at the point of use: prefetched they spill here (- 6 % at 2^23)
     exchange(x, 33 * kk, [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); }, rbase, [&](auto i_) {
         constexpr uint32_t i = decltype(i_)::value;
         return P(i * (N / 32));
@@ -132,11 +132,15 @@ __global__ __launch_bounds__(512, 4) void k_colsw(const v2f *__restrict__ in, v2
     const uint32_t soff = tile * (CW * 8);
     const uint32_t rstep = pitch * 8;  // bytes per matrix row
 
+    constexpr int PF = FWA_PF_COLSW;
+    Twiddles<32, N> w0;
+    if constexpr (PF & 1) twiddle_fetch<32, N>(w0, tw, kk);
     v2f x[32];
     FWA_ENTRY_HOOK();
     FWA_STAMP(0);
     static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_NT>(rin, voff, soff + (m * T) * rstep); });
     FWA_STAMP(1);
+    if constexpr (PF & 4) twiddle_fetch<32, N>(w0, tw, kk);
     const uint32_t col = tile * CW + c;
     auto look = [&](uint32_t e) { return cmul(tw_hi[e >> 10], tw_lo[e & 1023]); };  // W_n^e, e < n
     tq[kk * CW + c] = look(col * (32 * kk));           // R1 == T rows: one per thread
@@ -144,7 +148,8 @@ __global__ __launch_bounds__(512, 4) void k_colsw(const v2f *__restrict__ in, v2
     const v2f A = look(col * kk);
 
     fft_reg<32, DIR>(x);
-    twiddle_outputs<32, N, DIR>(x, tw, kk);
+    if constexpr (PF & 5) twiddle_apply<32, N, DIR>(x, w0);
+    else twiddle_outputs<32, N, DIR>(x, tw, kk);
     constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
     auto wpos = [](auto r_) { return (uint32_t)brev<32>(decltype(r_)::value); };
     auto rpos = [&](auto i_) { constexpr uint32_t i = decltype(i_)::value; return P((i / R1) * T + (i % R1) * 32); };

@@ -4,6 +4,18 @@
 #pragma once
 #include "small32_common.h"
 
+// Where the stage-0 twiddle look-ups of k_rows32 / k_colsw are issued (as small32_kernel.h's PREFETCH: bit 0 = before the
+// data loads, bit 2 = right behind them, 0 = at the point of use).  These passes are bound by their access pattern, not by
+// an exposed look-up: one library per value, interleaved in one process (tools/build_variant.sh, tools/ab_libs.py,
+// profiles/round5/ab_twiddle_prefetch_pass_kernels.jsonl), the 2^16 .. 2^19 plans gain 0.3-1.4 % with the look-ups first,
+// 2^21 / 2^22 (2048 / 4096-point rows) nothing; k_cols32 spills with them (2^23: - 6 %) and keeps them at the point of use.
+#ifndef FWA_PF_ROWS32
+#define FWA_PF_ROWS32 1
+#endif
+#ifndef FWA_PF_COLSW
+#define FWA_PF_COLSW 1
+#endif
+
 namespace fwa {
 
 // ---------------------------------------------------------------------------
@@ -87,13 +99,23 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
     constexpr auto P = [](uint32_t p) constexpr { return p + (p >> 5); };
     const uint32_t t_hi = t >> 5, t_lo = t & 31;
 
+    constexpr int PF = LGN <= 10 ? FWA_PF_ROWS32 : 0;   // 512 / 1024-point rows (the 2^16 .. 2^19 plans)
+    Twiddles<32, N> w0;
+    Twiddles<R1, N> w1[B1];
+    if constexpr (PF & 1) twiddle_fetch<32, N>(w0, tw, t);
+    if constexpr (!TWO && (PF & 2))
+        static_for<0, B1>([&](auto b_) { constexpr int b = decltype(b_)::value; twiddle_fetch<R1, N>(w1[b], tw, (t + b * T) & ~31u); });
     v2f x[32];
     FWA_ENTRY_HOOK();
     FWA_STAMP_B(0);
     static_for<0, 32>([&](auto m_) { constexpr int m = decltype(m_)::value; x[m] = buf_load<AUX_DEFAULT>(rin, voff, m * mstep); });
     FWA_STAMP_B(1);
+    if constexpr (PF & 4) twiddle_fetch<32, N>(w0, tw, t);
+    if constexpr (!TWO && (PF & 8))
+        static_for<0, B1>([&](auto b_) { constexpr int b = decltype(b_)::value; twiddle_fetch<R1, N>(w1[b], tw, (t + b * T) & ~31u); });
     fft_reg<32, DIR>(x);
-    twiddle_outputs<32, N, DIR>(x, tw, t);
+    if constexpr (PF & 5) twiddle_apply<32, N, DIR>(x, w0);
+    else twiddle_outputs<32, N, DIR>(x, tw, t);
     // transposed store role: output K2 of row r goes to element (16*tile + r) + n1*K2
     const uint32_t voff_o = (kk * n1 + r) * 8;
     const uint32_t soff_o = tile * (RW * 8);
@@ -123,7 +145,8 @@ __global__ __launch_bounds__((RW << (LGN - 5)), 4) void k_rows32(const v2f *__re
             v2f(&z)[R1] = *reinterpret_cast<v2f(*)[R1]>(&x[b * R1]);
             fft_reg<R1, DIR>(z);
             const uint32_t idx = t + b * T, sJ = idx & ~31u;
-            twiddle_outputs<R1, N, DIR>(z, tw, sJ);
+            if constexpr (PF & 10) twiddle_apply<R1, N, DIR>(z, w1[b]);
+            else twiddle_outputs<R1, N, DIR>(z, tw, sJ);
         });
         __syncthreads();
         // -> last stage (radix R2, J = N/R2, s = 0) in the storing role: butterfly idx = kk + b*T of row r

@@ -147,7 +147,7 @@ class Device:
 
     def __init__(self, ordinal=0, lab=False):
         self._L = _ffi.lib(lab)  # lab=True: the laboratory build (tools/ and bit-identity tests only)
-        self.lab = bool(lab)
+        self.lab = lab if isinstance(lab, str) else bool(lab)
         h = ctypes.c_void_p()
         _ffi.check(self._L.fwa_ctx_create(ordinal, ctypes.byref(h)), None, "fwa_ctx_create", self._L)
         self._h = h
