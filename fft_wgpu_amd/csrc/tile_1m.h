@@ -4,7 +4,7 @@
 #include "device_common.h"
 
 // Cache policy of the ring accesses (measured: stores sc1 = write-through, loads default); overridable at compile time
-// for the policy A/B of tools/run_r3_policies.sh only.
+// for the policy A/B of tools/archive/run_r3_policies.sh only.
 #ifndef FWA_RING_ST_AUX
 #define FWA_RING_ST_AUX AUX_SC1
 #endif
