@@ -12,7 +12,7 @@ import subprocess
 
 from conftest import ROOT
 
-DOCS = ["DESIGN.md", "HISTORY.md", "BASELINE.md", "README.md", "INTEGRATION.md", "profiles/round3/README.md", "profiles/round4/README.md",
+DOCS = ["DESIGN.md", "HISTORY.md", "BASELINE.md", "README.md", "INTEGRATION.md", "profiles/round3/README.md", "profiles/round4/README.md", "profiles/round5/README.md",
         "tools/README.md"]
 DATA_EXT = r"(?:jsonl|json|txt|csv|patch|npz)"
 
@@ -82,11 +82,11 @@ def test_design_is_the_current_state_and_history_keeps_the_ledgers():
     for frozen in ("2^20 is frozen", "2^15 is closed", "n > 2^24", "laboratory library is frozen"):
         assert frozen in design
     assert "unmeasured on more than one gpu" in design.lower()
-    for ledger in ("## Round 4", "## Round 3 ledger", "## Round 2 ledger"):
+    for ledger in ("## Round 5", "## Round 4", "## Round 3 ledger", "## Round 2 ledger"):
         assert ledger in history and ledger not in design
     # the lines the round-3 review named as stale are gone
     assert "skewed to 17 mod 32" not in design and "skewed to 17 mod 32 floats.  512-point" not in history
     assert "512 MiB 23.0" in history and "26.6 ms" in history             # all four ring-rotate rows, group = 32 beside them
     # README's headline is the driver's figure
     readme = open(os.path.join(ROOT, "README.md")).read()
-    assert "199.9" in readme and "0.400" in readme
+    assert "203.1" in readme and "0.406" in readme and "BENCH_r04.json" in readme
