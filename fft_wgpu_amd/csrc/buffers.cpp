@@ -95,7 +95,8 @@ static int32_t peer_kind(fwa_ctx *a, fwa_ctx *b, int32_t *kind)
         if (std::find(c->peers_enabled.begin(), c->peers_enabled.end(), o->device) != c->peers_enabled.end()) continue;
         HIP_TRY(c, hipSetDevice(c->device));
         hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail_hip(c, e, "hipDeviceEnablePeerAccess");
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            return fail_hip(c, e, "hipDeviceEnablePeerAccess");
         (void)hipGetLastError();
         c->peers_enabled.push_back(o->device);
     }
@@ -127,15 +128,16 @@ int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint
         HIP_TRY(on, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, raw(stream)));
         return FWA_OK;
     }
-    // two devices (one process driving several contexts: SURVEY.md 8(e)): an explicit peer copy, or a status code -- never a
-    // pointer the current device cannot reach handed to a plain device-to-device copy
+    // two devices (one process driving several contexts: SURVEY.md 8(e)): an explicit peer copy, or a status code --
+    // never a pointer the current device cannot reach handed to a plain device-to-device copy
     int32_t kind = 0;
     int32_t st = peer_kind(dst->ctx, const_cast<fwa_ctx *>(src->ctx), &kind);
     if (st) return st;
     if (kind != 2)
         return fail(dst->ctx, FWA_ERR_UNSUPPORTED,
                     "devices " + std::to_string(src->ctx->device) + " and " + std::to_string(dst->ctx->device) +
-                        " have no peer access: stage through the host (fwa_buf_download / fwa_buf_upload) or move the slab with fwa_comm_*");
+                        " have no peer access: stage through the host (fwa_buf_download / fwa_buf_upload) or move the "
+                        "slab with fwa_comm_*");
     USE_DEVICE(on);
     HIP_TRY(on, hipMemcpyPeerAsync(d, dst->ctx->device, s, src->ctx->device, bytes, raw(stream)));
     return FWA_OK;
@@ -192,9 +194,11 @@ int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_str
     if (bytes > dst->bytes || bytes > src->bytes || (bytes & 15))
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
     USE_DEVICE(dst->ctx);
-    // dst == src: an in-place streaming pass (every line read, then written back) -- the normalize kernel with scale 1:
-    // 64-KiB chunk per workgroup, every wave walks 16 KiB with 32 nt loads in flight: the fastest streaming shape on this part
-    hipError_t e = (dst->p == src->p) ? fwa::launch_scale(static_cast<const v2f *>(src->p), static_cast<v2f *>(dst->p), bytes / 8, 1.0f, raw(stream))
+    // dst == src: an in-place streaming pass (every line read, then written back) -- the normalize kernel with scale
+    // 1: 64-KiB chunk per workgroup, every wave walks 16 KiB with 32 nt loads in flight: the fastest streaming shape
+    // on this part
+    hipError_t e = (dst->p == src->p) ? fwa::launch_scale(static_cast<const v2f *>(src->p), static_cast<v2f *>(dst->p),
+                                                          bytes / 8, 1.0f, raw(stream))
                                       : fwa::launch_copy(src->p, dst->p, bytes, raw(stream));
     if (e != hipSuccess) return fail_hip(dst->ctx, e, "copy launch", FWA_ERR_LAUNCH);
     return FWA_OK;

@@ -1,13 +1,13 @@
 // comm.cpp -- fwa_comm_*: moving slabs of whole transforms between the GPUs of one node over RCCL (xGMI).
 //
 // The transform itself never communicates (reference src/kernel/fft4.wgsl:21-23: one `offset` per workgroup, no
-// cross-transform access).  This file only serves callers whose batch starts -- or must end up -- on one
-// GPU while the other GPUs belong to OTHER processes (one process per GPU, the deployment north_star names): root
-// scatters slabs with grouped ncclSend / ncclRecv, the mirror gathers.  One process that drives several devices itself
-// needs none of it: it holds every pointer and moves slabs with fwa_buf_copy (peer copies, buffers.cpp).
+// cross-transform access).  This file only serves callers whose batch starts -- or must end up -- on
+// one GPU while the other GPUs belong to OTHER processes (one process per GPU, the deployment north_star names): root
+// scatters slabs with grouped ncclSend / ncclRecv, the mirror gathers.  One process that drives several devices
+// itself needs none of it: it holds every pointer and moves slabs with fwa_buf_copy (peer copies, buffers.cpp).
 //
-// librccl is loaded on the first fwa_comm_* call (dlopen), not linked: a caller that never shards pays neither its load time
-// nor its dependency.
+// librccl is loaded on the first fwa_comm_* call (dlopen), not linked: a caller that never shards pays neither its
+// load time nor its dependency.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -77,7 +77,8 @@ int32_t need_rccl(const fwa_ctx *ctx, Rccl **out)
 
 int32_t fail_nccl(const fwa_ctx *ctx, Rccl *r, ncclResult_t e, const char *what)
 {
-    return fwa_int::fail(ctx, FWA_ERR_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
+    return fwa_int::fail(ctx, FWA_ERR_HIP,
+                         std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
 }
 
 static_assert(sizeof(ncclUniqueId) == FWA_COMM_ID_BYTES, "FWA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
@@ -89,11 +90,12 @@ struct Piece {  // one side of a point-to-point transfer: bytes at ptr, to / fro
 };
 
 // ranges of fwa_buf handles are checked by the callers through these two accessors of the public ABI
-bool in_range(const fwa_buf *b, uint64_t off, uint64_t bytes) { return off <= fwa_buf_size(b) && bytes <= fwa_buf_size(b) - off; }
+bool in_range(const fwa_buf *b, uint64_t off, uint64_t bytes) { return off <= fwa_buf_size(b)
+                                                               && bytes <= fwa_buf_size(b) - off; }
 char *at(const fwa_buf *b, uint64_t off) { return static_cast<char *>(fwa_buf_device_ptr(b)) + off; }
 
-// Grouped sends and receives of this rank on `stream`; a piece addressed to the rank itself must have its partner in the
-// same group (RCCL pairs them up as a local copy).
+// Grouped sends and receives of this rank on `stream`; a piece addressed to the rank itself must have its partner in
+// the same group (RCCL pairs them up as a local copy).
 int32_t exchange(fwa_comm *c, const Piece *sends, size_t ns, const Piece *recvs, size_t nr, fwa_stream *stream)
 {
     Rccl *r = nullptr;
@@ -104,9 +106,11 @@ int32_t exchange(fwa_comm *c, const Piece *sends, size_t ns, const Piece *recvs,
     ncclResult_t e = r->GroupStart();
     if (e != ncclSuccess) return fail_nccl(c->ctx, r, e, "ncclGroupStart");
     for (size_t i = 0; i < ns && e == ncclSuccess; ++i)
-        if (sends[i].peer >= 0 && sends[i].bytes) e = r->Send(sends[i].ptr, sends[i].bytes, ncclInt8, sends[i].peer, c->comm, hs);
+        if (sends[i].peer >= 0 && sends[i].bytes) e = r->Send(sends[i].ptr, sends[i].bytes, ncclInt8, sends[i].peer,
+                                                              c->comm, hs);
     for (size_t i = 0; i < nr && e == ncclSuccess; ++i)
-        if (recvs[i].peer >= 0 && recvs[i].bytes) e = r->Recv(recvs[i].ptr, recvs[i].bytes, ncclInt8, recvs[i].peer, c->comm, hs);
+        if (recvs[i].peer >= 0 && recvs[i].bytes) e = r->Recv(recvs[i].ptr, recvs[i].bytes, ncclInt8, recvs[i].peer,
+                                                              c->comm, hs);
     const ncclResult_t ge = r->GroupEnd();
     if (e != ncclSuccess) return fail_nccl(c->ctx, r, e, "ncclSend/ncclRecv");
     if (ge != ncclSuccess) return fail_nccl(c->ctx, r, ge, "ncclGroupEnd");
@@ -144,7 +148,7 @@ int32_t fwa_comm_create(fwa_ctx *ctx, const uint8_t id[FWA_COMM_ID_BYTES], int32
     if (!c) return fwa_int::fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
     ncclUniqueId u;
     std::memcpy(&u, id, FWA_COMM_ID_BYTES);
-    // collective over the `world` callers that hold the same id: one rank per device (RCCL refuses two ranks on one GPU)
+    // collective over the `world` callers that hold the same id: one rank per device (RCCL refuses two on one GPU)
     const ncclResult_t e = r->CommInitRank(&c->comm, world, u, rank);
     if (e != ncclSuccess) {
         delete c;
@@ -178,17 +182,24 @@ int32_t fwa_comm_get_i64(const fwa_comm *comm, const char *key, int64_t *value)
     return FWA_OK;
 }
 
-int32_t fwa_comm_sendrecv(fwa_comm *comm, const fwa_buf *send, uint64_t send_offset, uint64_t send_bytes, int32_t send_to,
-                          fwa_buf *recv, uint64_t recv_offset, uint64_t recv_bytes, int32_t recv_from, fwa_stream *stream)
+int32_t fwa_comm_sendrecv(fwa_comm *comm, const fwa_buf *send, uint64_t send_offset, uint64_t send_bytes,
+                          int32_t send_to,
+                          fwa_buf *recv, uint64_t recv_offset, uint64_t recv_bytes, int32_t recv_from,
+                              fwa_stream *stream)
 {
     if (!comm) return fwa_int::fail(nullptr, FWA_ERR_INVALID_ARG, "comm is NULL");
     fwa_ctx *ctx = comm->ctx;
-    if (send_to >= comm->world || recv_from >= comm->world) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "peer rank out of range");
-    if (send_to >= 0 && (!send || !in_range(send, send_offset, send_bytes))) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "send range exceeds buffer");
-    if (recv_from >= 0 && (!recv || !in_range(recv, recv_offset, recv_bytes))) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "receive range exceeds buffer");
+    if (send_to >= comm->world || recv_from >= comm->world)
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "peer rank out of range");
+    if (send_to >= 0 && (!send || !in_range(send, send_offset, send_bytes)))
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "send range exceeds buffer");
+    if (recv_from >= 0 && (!recv || !in_range(recv, recv_offset, recv_bytes)))
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "receive range exceeds buffer");
     if ((send_to == comm->rank) != (recv_from == comm->rank) || (send_to == comm->rank && send_bytes != recv_bytes))
-        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "a send to this rank itself needs the matching receive in the same call");
-    if (stream && fwa_int::stream_ctx(stream) != ctx) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "the stream belongs to another context");
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG,
+                             "a send to this rank itself needs the matching receive in the same call");
+    if (stream && fwa_int::stream_ctx(stream) != ctx)
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "the stream belongs to another context");
     const Piece s{send_to >= 0 ? at(send, send_offset) : nullptr, send_bytes, send_to};
     const Piece r{recv_from >= 0 ? at(recv, recv_offset) : nullptr, recv_bytes, recv_from};
     return exchange(comm, &s, 1, &r, 1, stream);
@@ -196,11 +207,11 @@ int32_t fwa_comm_sendrecv(fwa_comm *comm, const fwa_buf *send, uint64_t send_off
 
 // Slabs follow fwa_slab(batch, rank, world): rank r owns transforms [first_r, first_r + count_r).
 //
-// The point-to-point pieces one rank posts in a scatter or a gather -- pure host logic (no device, no RCCL), so that the
-// table both collectives are built on can be checked for every world size without a second GPU.  A rank other than the
-// root posts ONE piece (its whole slab, peer = root, offset 0 into its slab buffer); the root posts `world` pieces, piece
-// p = rank p's slab at byte offset first_p * 8 * fft_len of the full batch, peer = p, and peer = -1 for its own slab
-// (moved by a device copy on the same stream instead).
+// The point-to-point pieces one rank posts in a scatter or a gather -- pure host logic (no device, no RCCL), so that
+// the table both collectives are built on can be checked for every world size without a second GPU.  A rank other
+// than the root posts ONE piece (its whole slab, peer = root, offset 0 into its slab buffer); the root posts `world`
+// pieces, piece p = rank p's slab at byte offset first_p * 8 * fft_len of the full batch, peer = p, and peer = -1 for
+// its own slab (moved by a device copy on the same stream instead).
 int32_t fwa_comm_pieces(uint64_t batch, uint32_t fft_len, int32_t root, int32_t rank, int32_t world, uint64_t *offset,
                         uint64_t *bytes, int32_t *peer, int32_t *n_pieces)
 {
@@ -229,7 +240,8 @@ namespace {
 
 // scatter (gather = false): root's `full` -> every rank's `slab`; gather: the mirror image.  Host memory: two small
 // vectors per call on the root (these calls, unlike fwa_plan_exec, are not allocation-free).
-int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *slab, const fwa_buf *full, uint32_t fft_len,
+int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *slab, const fwa_buf *full,
+                   uint32_t fft_len,
                    uint64_t batch, fwa_stream *stream)
 {
     if (!comm || !slab || !fft_len)
@@ -242,7 +254,8 @@ int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *sla
     std::vector<uint64_t> off((size_t)(is_root ? comm->world : 1)), len(off.size());
     std::vector<int32_t> peer(off.size());
     int32_t np = 0;
-    int32_t st = fwa_comm_pieces(batch, fft_len, root, comm->rank, comm->world, off.data(), len.data(), peer.data(), &np);
+    int32_t st = fwa_comm_pieces(batch, fft_len, root, comm->rank, comm->world, off.data(), len.data(), peer.data(),
+                                 &np);
     if (st) return st;
     const uint64_t tb = 8ull * fft_len;
     uint64_t first = 0, count = 0;
@@ -253,9 +266,11 @@ int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *sla
         const Piece one{at(slab, 0), len[0], peer[0]};
         return gather ? exchange(comm, &one, 1, nullptr, 0, stream) : exchange(comm, nullptr, 0, &one, 1, stream);
     }
-    if (!full || !in_range(full, 0, batch * tb)) return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root needs the full batch buffer");
+    if (!full || !in_range(full, 0, batch * tb))
+        return fwa_int::fail(ctx, FWA_ERR_INVALID_ARG, "root needs the full batch buffer");
     std::vector<Piece> pieces((size_t)np);
-    for (int32_t p = 0; p < np; ++p) pieces[(size_t)p] = Piece{at(full, off[(size_t)p]), len[(size_t)p], peer[(size_t)p]};
+    for (int32_t p = 0; p < np; ++p) pieces[(size_t)p] = Piece{at(full, off[(size_t)p]), len[(size_t)p],
+                                                               peer[(size_t)p]};
     st = gather ? exchange(comm, nullptr, 0, pieces.data(), pieces.size(), stream)
                 : exchange(comm, pieces.data(), pieces.size(), nullptr, 0, stream);
     if (st) return st;

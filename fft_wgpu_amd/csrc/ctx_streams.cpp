@@ -26,8 +26,8 @@ int32_t fail(const fwa_ctx *ctx, int32_t st, const std::string &msg)
 }
 int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t st)
 {
-    // HIP keeps the last error until somebody reads it; the launch wrappers read it after every launch, so an error that
-    // has been reported here (e.g. an out-of-memory hipMalloc) must not surface again as a bogus launch failure later
+    // HIP keeps the last error until somebody reads it; the launch wrappers read it after every launch, so an error
+    // that has been reported here (e.g. an out-of-memory hipMalloc) must not surface again as a bogus launch failure
     (void)hipGetLastError();
     std::string m = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     if (e == hipErrorOutOfMemory) st = FWA_ERR_OUT_OF_MEMORY;
@@ -36,20 +36,21 @@ int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t st)
 const char *thread_error_string() { return g_err.c_str(); }
 
 // Streams that overlap.  Two HIP streams do not always run side by side on this stack: which hardware queue a new
-// stream lands on depends on what the process created and destroyed before, and a pair that shares one runs strictly one
-// after the other -- a pipelined plan whose two chains shared a queue took the single-chain time on every exec (+15 %:
-// profiles/round3/probe_plan_instance_modes.txt), a host pipeline whose transfer streams shared one moved 21 GB/s each way
-// instead of 44.  So a stream created by this library is accepted only if a memory-free spin kernel on it overlaps the same
-// kernel on its `peers` (time on all of them at once < single + half a spin); a rejected candidate stays alive until the
-// search ends so that the runtime cannot hand the same queue back.  Best effort: after 6 rejections the last candidate is
-// kept (a process with more streams than the runtime has hardware queues cannot overlap them all).
+// stream lands on depends on what the process created and destroyed before, and a pair that shares one runs strictly
+// one after the other -- a pipelined plan whose two chains shared a queue took the single-chain time on every exec
+// (+15 %: profiles/round3/probe_plan_instance_modes.txt), a host pipeline whose transfer streams shared one moved 21
+// GB/s each way instead of 44.  So a stream created by this library is accepted only if a memory-free spin kernel on
+// it overlaps the same kernel on its `peers` (time on all of them at once < single + half a spin); a rejected
+// candidate stays alive until the search ends so that the runtime cannot hand the same queue back.  Best effort:
+// after 6 rejections the last candidate is kept (a process with more streams than the runtime has hardware queues
+// cannot overlap them all).
 //
 // Side effects, and how a caller controls them (include/fft_wgpu_amd.h, "Threading"): the check launches ~40-us spin
-// kernels on the candidate, on the peers and on a private base stream of its own -- never on the null stream -- and runs
-// only when there are peers to overlap with (a plan with one chain, or a context's first stream, costs nothing).  It is
-// refused with FWA_ERR_UNSUPPORTED while a stream of this context is capturing a graph (its timing would be meaningless and
-// the peers may be the capturing streams), and fwa_ctx_set_i64(ctx, "chain_check", 0) turns it off: streams are then taken
-// as the runtime hands them out.
+// kernels on the candidate, on the peers and on a private base stream of its own -- never on the null stream -- and
+// runs only when there are peers to overlap with (a plan with one chain, or a context's first stream, costs nothing).
+// It is refused with FWA_ERR_UNSUPPORTED while a stream of this context is capturing a graph (its timing would be
+// meaningless and the peers may be the capturing streams), and fwa_ctx_set_i64(ctx, "chain_check", 0) turns it off:
+// streams are then taken as the runtime hands them out.
 bool any_stream_capturing(const fwa_ctx *ctx)
 {
     for (const fwa_stream *s : ctx->live_streams) {
@@ -70,8 +71,8 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
     }
     if (any_stream_capturing(ctx))
         return fail(ctx, FWA_ERR_UNSUPPORTED,
-                    "a stream of this context is capturing a graph: create plans and streams before the capture begins, or "
-                    "turn the stream-overlap check off with fwa_ctx_set_i64(ctx, \"chain_check\", 0)");
+                    "a stream of this context is capturing a graph: create plans and streams before the capture "
+                    "begins, or turn the stream-overlap check off with fwa_ctx_set_i64(ctx, \"chain_check\", 0)");
     constexpr uint32_t TICKS = 4000, BLOCKS = 256;  // 40 us, one wave per CU
     hipEvent_t e0 = nullptr, e1 = nullptr, fork = nullptr;
     hipStream_t base = nullptr;  // the check's own fork / join stream: nothing here touches the null stream
@@ -81,7 +82,8 @@ int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, 
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-    auto timed = [&](const std::vector<hipStream_t> &set, float *us) {  // spin on every stream of `set`, forked from / joined to `base`
+    // spin on every stream of `set`, forked from / joined to `base`
+    auto timed = [&](const std::vector<hipStream_t> &set, float *us) {
         float best = 1e30f;
         for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
             while (done.size() < set.size() && e == hipSuccess) {
@@ -181,7 +183,8 @@ int32_t fwa_device_count(int32_t *count)
     return FWA_OK;
 }
 
-int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int32_t *compute_units, uint64_t *hbm_bytes,
+int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int32_t *compute_units,
+                        uint64_t *hbm_bytes,
                         int32_t *usable)
 {
     if (name && name_cap) name[0] = 0;
@@ -194,7 +197,8 @@ int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int
         (void)hipGetLastError();
         return fail(nullptr, FWA_ERR_NO_DEVICE, "no HIP device visible");
     }
-    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, FWA_ERR_INVALID_ARG, "device ordinal out of range");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, FWA_ERR_INVALID_ARG, "device ordinal out of range");
     hipDeviceProp_t prop{};
     e = hipGetDeviceProperties(&prop, device_ordinal);
     if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
@@ -208,8 +212,8 @@ int32_t fwa_device_info(int32_t device_ordinal, char *name, size_t name_cap, int
     return FWA_OK;
 }
 
-// The slab rule of SURVEY.md 8(e): contiguous runs of whole transforms, sizes differing by at most one.  Pure host logic;
-// fft_wgpu_amd/sharding.py::slab and fft_wgpu::slab (include/fft_wgpu.hpp) are this function.
+// The slab rule of SURVEY.md 8(e): contiguous runs of whole transforms, sizes differing by at most one.  Pure host
+// logic; fft_wgpu_amd/sharding.py::slab and fft_wgpu::slab (include/fft_wgpu.hpp) are this function.
 int32_t fwa_slab(uint64_t batch, int32_t rank, int32_t world, uint64_t *first, uint64_t *count)
 {
     if (!first || !count) return fail(nullptr, FWA_ERR_INVALID_ARG, "first/count is NULL");
@@ -243,7 +247,8 @@ int32_t fwa_ctx_create(int32_t device_ordinal, fwa_ctx **out)
     }
     if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
         int32_t st = fail(nullptr, FWA_ERR_NO_DEVICE,
-                          std::string("device is ") + ctx->prop.gcnArchName + ", this library is built for gfx950 only");
+                          std::string("device is ") + ctx->prop.gcnArchName +
+                              ", this library is built for gfx950 only");
         delete ctx;
         return st;
     }
@@ -306,8 +311,8 @@ int32_t fwa_ctx_set_i64(fwa_ctx *ctx, const char *key, int64_t value)
     if (!ctx || !key) return fail(ctx, FWA_ERR_INVALID_ARG, "NULL argument");
     const std::string k(key);
     if (k == "chain_check") {
-        // 0: streams this library creates (the chain streams of pipelined plans, fwa_stream_create) are no longer tested
-        // for overlap with spin kernels (overlapping_stream above)
+        // 0: streams this library creates (the chain streams of pipelined plans, fwa_stream_create) are no longer
+        // tested for overlap with spin kernels (overlapping_stream above)
         if (value != 0 && value != 1) return fail(ctx, FWA_ERR_INVALID_ARG, "chain_check is 0 or 1");
         ctx->chain_check = value;
         return FWA_OK;
@@ -337,7 +342,8 @@ int32_t fwa_stream_create(fwa_ctx *ctx, fwa_stream **out)
     // checked to overlap the (up to two) streams this context created most recently: a caller that makes a transfer
     // stream and a compute stream back to back gets two that really run side by side (overlapping_stream above)
     hipStream_t s;
-    std::vector<hipStream_t> peers(ctx->user_streams.end() - (std::ptrdiff_t)std::min<size_t>(2, ctx->user_streams.size()),
+    std::vector<hipStream_t> peers(ctx->user_streams.end() - (std::ptrdiff_t)std::min<size_t>(2,
+                                                                                              ctx->user_streams.size()),
                                    ctx->user_streams.end());
     int32_t rc = overlapping_stream(ctx, peers, &s);
     if (rc) return rc;
@@ -391,7 +397,8 @@ int32_t fwa_stream_destroy(fwa_stream *stream)
 
 int32_t fwa_stream_wait_stream(fwa_stream *stream, fwa_stream *other)
 {
-    if (!stream || !other || !stream->ctx) return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL or its context has been destroyed");
+    if (!stream || !other || !stream->ctx)
+        return fail(nullptr, FWA_ERR_INVALID_ARG, "stream is NULL or its context has been destroyed");
     USE_DEVICE(stream->ctx);
     hipEvent_t ev;
     HIP_TRY(stream->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));

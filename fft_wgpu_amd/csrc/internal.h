@@ -37,7 +37,8 @@ enum fwa_path : int64_t {
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,    // n = 1
     PATH_RING_1M = 5,     // n = 2^20: the same two passes as ONE persistent launch with a small ring (k_ring_1m)
-    PATH_TEAM = 8,        // n = 2^16 .. 2^18: both passes in one persistent launch, intermediate in one XCD's L2 (k_team)
+    // n = 2^16 .. 2^18: both passes in one persistent launch, intermediate in one XCD's L2 (k_team)
+    PATH_TEAM = 8,
     PATH_TILED = 7,       // n = N1*N2[*N3], each 64..1024: 2-3 k_tile passes
 };
 
@@ -79,7 +80,8 @@ struct fwa_ctx {
     std::vector<hipStream_t> user_streams;  // alive streams made by fwa_stream_create, oldest first
     std::vector<fwa_stream *> live_streams; // every alive fwa_stream handle of this context (created or wrapped)
     int64_t n_chain_checks = 0, n_chain_rejects = 0, chain_pair_us = 0, chain_single_us = 0;
-    int64_t chain_check = 1;                // fwa_ctx_set_i64("chain_check", 0): new streams are taken as the runtime hands them out
+    // fwa_ctx_set_i64("chain_check", 0): new streams are taken as the runtime hands them out
+    int64_t chain_check = 1;
     std::vector<int> peers_enabled;         // device ordinals this context's device has peer access to (enabled once)
 };
 struct fwa_stream {
@@ -121,22 +123,31 @@ struct fwa_plan {
     int64_t group = 16;            // transforms per launch
     int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
-    int64_t xcd_swizzle = -1;      // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
-                                   // +2 %; off for the tiled path: 1-5 % faster without, profiles/round2/sweep_xcd_swizzle.jsonl)
-    int64_t rows32 = 1;            // two-pass tiled plans with a 512..2048-point second factor: 1 = k_rows32 as last pass
+    // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
+    int64_t xcd_swizzle = -1;
+                                   // +2 %; off for the tiled path: 1-5 % faster without,
+                                   // profiles/round2/sweep_xcd_swizzle.jsonl)
+    // two-pass tiled plans with a 512..2048-point second factor: 1 = k_rows32 as last pass
+    int64_t rows32 = 1;
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
-    int64_t colsw = 0;             // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) as pass A, 0 = k_tile
+    // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) as pass A, 0 = k_tile
+    int64_t colsw = 0;
     int64_t tile_ring = 1;         // k_colsw + k_rows32: 1 = tile-contiguous ring slab, 0 = matrix layout
-    int64_t ring_rotate = 1;       // laboratory: the ring is this many times larger and the groups rotate through it (same
+    // laboratory: the ring is this many times larger and the groups rotate through it (same
+    int64_t ring_rotate = 1;
                                    // launches, larger cache footprint: prices what the Infinity Cache gives the ring)
-    int64_t wave = 1;              // n = 512: 1 = k_wave512 (wave-private, a wave's four transforms one at a time: 0.78 of the
+    // n = 512: 1 = k_wave512 (wave-private, a wave's four transforms one at a time: 0.78 of the
+    int64_t wave = 1;
                                    // roofline against 0.71, profiles/round5/ab_wave512.jsonl), 0 = k_small32<9>
-    int64_t small_reg = 1;         // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
+    // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
+    int64_t small_reg = 1;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
-    hipStream_t last_stream = nullptr;  // the caller's stream of the last exec that used the ring: fwa_plan_destroy waits for the
-    bool ran_on_stream = false;         // work enqueued there (an event per exec would cost 4-5 us on the 1-3-launch latency shapes)
+    // the caller's stream of the last exec that used the ring: fwa_plan_destroy waits for the
+    hipStream_t last_stream = nullptr;
+    // work enqueued there (an event per exec would cost 4-5 us on the 1-3-launch latency shapes)
+    bool ran_on_stream = false;
     // persistent 2^20 pipeline (PATH_RING_1M)
     uint32_t *ring_ctl = nullptr;  // ticket, error word, per-transform hand-off counters
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
@@ -144,12 +155,14 @@ struct fwa_plan {
     int64_t wgs = 512;             // persistent workgroups (2 per CU)
     // L2-resident team pipeline (PATH_TEAM)
     int64_t max_teams = 0;         // teams (= slabs) per XCD; 0 = as many as fit 3 MiB of an XCD's 4-MiB L2
-    int64_t inject_fail_group = -1;  // laboratory: the launch of this group fails once (error path of run_groups under test)
+    // laboratory: the launch of this group fails once (error path of run_groups under test)
+    int64_t inject_fail_group = -1;
 };
 
 namespace fwa_int {
 
-// ---- errors (ctx_streams.cpp): record the message on the context (or thread-locally without one), return the status ----
+// ---- errors (ctx_streams.cpp): record the message on the context (or thread-locally without one), return the status
+//   ----
 int32_t fail(const fwa_ctx *ctx, int32_t status, const std::string &msg);
 int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t status = FWA_ERR_HIP);
 const char *thread_error_string();

@@ -21,8 +21,8 @@ namespace fwa_int {
 // `batch` separates two regimes (profiles/round2/sweep_small_batch_latency.jsonl):
 //  * throughput (n * batch > 2^20 samples): few passes of fat tiles -- a 1024-point first pass (k_p1_gen / the 2^20
 //    pipeline, 64 KiB tiles of 512 threads) and 32-point-per-thread rows;
-//  * latency (at most 2^20 samples in flight, or a single 2^21 / 2^22 transform, or fewer than FEW_1M transforms of 2^20):
-//    fat tiles leave most of the 256 CUs idle (one 2^16 transform = FOUR 1024 x 16 tiles), so the plan uses the
+//  * latency (at most 2^20 samples in flight, or a single 2^21 / 2^22 transform, or fewer than FEW_1M transforms of
+//    2^20): fat tiles leave most of the 256 CUs idle (one 2^16 transform = FOUR 1024 x 16 tiles), so the plan uses the
 //    smallest tiles instead -- balanced two passes up to 2^17, balanced three passes of 64/128-point tiles above
 //    (2^16 x 1: 11.9 us against 16.2; 2^18 x 1: 12.7 against 18.4; 2^20 x 1: 19 against 24).
 constexpr uint64_t FEW_1M = 4;
@@ -33,25 +33,31 @@ int64_t choose_path(uint32_t n, uint64_t batch, uint32_t lf[3], bool *colsw)
     const uint32_t lg = ilog2(n);
     if (n == 1) return PATH_IDENTITY;
     if (n <= 32768) { lf[0] = lg; return PATH_SMALL; }
-    const bool few = (lg < 20 && batch <= ((1ull << 20) >> lg)) || (lg == 20 && batch < FEW_1M) || ((lg == 21 || lg == 22) && batch == 1);
+    const bool few = (lg < 20 && batch <= ((1ull << 20) >> lg)) || (lg == 20 && batch < FEW_1M)
+        || ((lg == 21 || lg == 22) && batch == 1);
     if (n == (1u << 20) && !few) { lf[0] = lf[1] = 10; return PATH_TWOPASS_1M; }
     if (n <= (1u << 30)) {
         // factors of 64..1024 each, 2048 for the rows of a two-pass plan (re-tunable: key "factors").  Throughput
-        // regime: two passes up to 2^19 and at 2^21 .. 2^23 (2048 / 4096-point passes), three otherwise; a 1024-point first pass (k_p1_gen) wherever the
-        // other factors stay >= 64, measured faster than a balanced split except at 2^22 (level)
-        // (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl).
-        // Round 3 (profiles/round3/sweep_colsw_32GiB.jsonl, sweep_factors_24_28_colsw.jsonl): short columns in wide tiles
+        // regime: two passes up to 2^19 and at 2^21 .. 2^23 (2048 / 4096-point passes), three otherwise; a 1024-point
+        // first pass (k_p1_gen) wherever the other factors stay >= 64, measured faster than a balanced split except
+        // at 2^22 (level) (profiles/round2/p1gen_sweep.jsonl, factor_sweep.jsonl, sweep_rows32.jsonl). Round 3
+        // (profiles/round3/sweep_colsw_32GiB.jsonl, sweep_factors_24_28_colsw.jsonl): short columns in wide tiles
         // (k_colsw: 256 x 64 / 512 x 32, 512- / 256-byte row segments) beat the 1024 x 16 tile of k_p1_gen as pass A
-        // wherever the last pass keeps <= 1024-point rows: 2^16 .. 2^19 +7-9 %, three-pass sizes 2^24 .. 2^28 +2-16 %.
-        if (!few && lg == 22) { lf[0] = 10; lf[1] = 12; }       // 1024 x 4096: k_p1_gen + k_rows32 (8 rows of 4096 per workgroup)
+        // wherever the last pass keeps <= 1024-point rows: 2^16 .. 2^19 + 7-9 %, three-pass sizes 2^24 .. 2^28 + 2-16 %
+        // 1024 x 4096: k_p1_gen + k_rows32 (8 rows of 4096 per workgroup)
+        if (!few && lg == 22) { lf[0] = 10; lf[1] = 12; }
         else if (!few && lg == 23) { lf[0] = 11; lf[1] = 12; }  // 2048 x 4096: k_cols32 + k_rows32
         else if (few && lg <= 17) { lf[0] = lg / 2; lf[1] = lg - lf[0]; }
         else if (!few && lg <= 18) { lf[0] = 8; lf[1] = lg - 8; if (colsw) *colsw = true; }   // 256 x (256 .. 1024)
         else if (!few && lg == 19) { lf[0] = 9; lf[1] = 10; if (colsw) *colsw = true; }       // 512 x 1024
         else if (!few && lg == 21) { lf[0] = 10; lf[1] = lg - 10; }
-        else if (!few && lg >= 24 && lg <= 28) { lf[0] = 9; lf[1] = (lg - 9) / 2; lf[2] = lg - 9 - lf[1]; if (colsw) *colsw = true; }
+        else if (!few && lg >= 24 && lg <= 28) {
+            lf[0] = 9; lf[1] = (lg - 9) / 2; lf[2] = lg - 9 - lf[1];
+            if (colsw) *colsw = true;
+        }
         else if (!few && lg >= 29) { lf[0] = 10; lf[1] = (lg - 10) / 2; lf[2] = lg - 10 - lf[1]; }
-        else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }  // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
+        // 16.4 us against 18.2 for 64 x 128 x 128 (sweep_factor_permutations_batch1.jsonl)
+        else if (few && lg == 20) { lf[0] = lf[1] = 6; lf[2] = 8; }
         else for (uint32_t i = 0; i < 3; ++i) lf[i] = lg / 3 + (i >= 3 - lg % 3 ? 1 : 0);
         return PATH_TILED;
     }
@@ -81,7 +87,8 @@ int32_t setup_path(fwa_plan *p)
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_small_done = true;
     }
-    if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M || (p->path == PATH_TILED && p->lf[0] == 10)) && !ctx->setup_1m_done) {
+    if ((p->path == PATH_TWOPASS_1M || p->path == PATH_RING_1M || (p->path == PATH_TILED && p->lf[0] == 10))
+        && !ctx->setup_1m_done) {
         hipError_t e = fwa::setup_1m_kernels();
 #ifdef FWA_LAB
         if (e == hipSuccess) e = fwa::setup_lab_1m_kernels();
@@ -170,9 +177,10 @@ static fwa_buf *result_buffer(fwa_plan *p)
     return (p->lg % 2 == 0) ? p->src : p->second;
 }
 
-// Block -> tile map of the tiled plans' kernels (xcd_map, device_common.h) when the caller has not set "xcd_swizzle": measured per
-// size at the 32-GiB footprint, three interleaved runs (profiles/round4/sweep_tiled_block_maps.jsonl): the k_colsw plans gain 2-4 %
-// from XCD-contiguous runs (2^17 .. 2^19: bit 0; 2^16 and 1024 x 2048: with the CU pairs, bits 0 + 2); 2^22 and up lose 1-10 %.
+// Block -> tile map of the tiled plans' kernels (xcd_map, device_common.h) when the caller has not set "xcd_swizzle":
+// measured per size at the 32-GiB footprint, three interleaved runs (profiles/round4/sweep_tiled_block_maps.jsonl):
+// the k_colsw plans gain 2-4 % from XCD-contiguous runs (2^17 .. 2^19: bit 0; 2^16 and 1024 x 2048: with the CU
+// pairs, bits 0 + 2); 2^22 and up lose 1-10 %.
 uint32_t tiled_swizzle_default(const fwa_plan *p)
 {
     if (p->lf[2]) return 0u;
@@ -190,7 +198,8 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
     fwa_ctx *ctx = plan->ctx;
     const uint64_t G = (uint64_t)plan->group, n_groups = (plan->batch + G - 1) / G;
     const size_t ns = plan->istreams.size();
-    if (plan->batch && !plan->ring) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
+    if (plan->batch && !plan->ring)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
     if (ns) {
         HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
         for (size_t i = 0; i < ns; ++i) HIP_TRY(ctx, hipStreamWaitEvent(plan->istreams[i], plan->ev_fork, 0));
@@ -204,9 +213,9 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
 #endif
         e = body(g, cnt, ns ? plan->istreams[c] : st, c);
     }
-    // Join the chains back to the caller's stream ALSO when a launch failed: the groups enqueued before the failure keep
-    // running on the chains, and whatever the caller enqueues next on `st` (a copy of the partial result, the free of the
-    // buffer) must be ordered behind them.
+    // Join the chains back to the caller's stream ALSO when a launch failed: the groups enqueued before the failure
+    // keep running on the chains, and whatever the caller enqueues next on `st` (a copy of the partial result, the
+    // free of the buffer) must be ordered behind them.
     hipError_t je = hipSuccess;
     for (size_t i = 0; i < ns; ++i) {
         hipError_t r = hipEventRecord(plan->idone[i], plan->istreams[i]);
@@ -230,18 +239,20 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
 {
     if (!plan) return FWA_OK;
     (void)hipSetDevice(plan->ctx->device);
-    // work of this plan may still be in flight on the caller's stream; the pooled ring must not be handed to the
-    // next plan before it has drained (hipFree would have synchronised implicitly).  Only THIS plan's last exec is
-    // waited for, through a marker on the stream that exec was enqueued on -- other streams and contexts keep running (a
-    // device-wide synchronise here stalled them all and is illegal while any stream captures a graph).  An exec that was
-    // captured into a graph enqueued nothing real: the plan must outlive the graphs that replay it.
+    // work of this plan may still be in flight on the caller's stream; the pooled ring must not be handed to the next
+    // plan before it has drained (hipFree would have synchronised implicitly).  Only THIS plan's last exec is waited
+    // for, through a marker on the stream that exec was enqueued on -- other streams and contexts keep running (a
+    // device-wide synchronise here stalled them all and is illegal while any stream captures a graph).  An exec that
+    // was captured into a graph enqueued nothing real: the plan must outlive the graphs that replay it.
     if (plan->frozen && plan->ring) {
         hipEvent_t ev = nullptr;
         bool waited = false;
-        // only a stream that is known to be alive can take the marker: the null stream, or a stream of this context's own
-        // making that has not been destroyed (HIP does not validate stream handles); otherwise the device-wide wait below
+        // only a stream that is known to be alive can take the marker: the null stream, or a stream of this context's
+        // own making that has not been destroyed (HIP does not validate stream handles); otherwise the device-wide
+        // wait below
         const auto &us = plan->ctx->user_streams;
-        const bool alive = plan->last_stream == nullptr || std::find(us.begin(), us.end(), plan->last_stream) != us.end();
+        const bool alive = plan->last_stream == nullptr
+            || std::find(us.begin(), us.end(), plan->last_stream) != us.end();
         if (plan->ran_on_stream && alive && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
             // everything this plan enqueued on its last caller stream precedes this marker
             if (hipEventRecord(ev, plan->last_stream) == hipSuccess) waited = hipEventSynchronize(ev) == hipSuccess;
@@ -249,7 +260,8 @@ int32_t fwa_plan_destroy(fwa_plan *plan)
         }
         if (!waited) {
             (void)hipGetLastError();
-            (void)hipDeviceSynchronize();  // the stream is gone or not ours (fwa_stream_wrap), or a laboratory persistent path
+            // the stream is gone or not ours (fwa_stream_wrap), or a laboratory persistent path
+            (void)hipDeviceSynchronize();
         }
     }
     Pipeline pl = take_pipeline(plan);
@@ -282,7 +294,8 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
         return fail(ctx, FWA_ERR_INVALID_ARG, "second buffer must have the size of the first");
     if (src2_or_null && src2_or_null->p == src->p && src->bytes)
         return fail(ctx, FWA_ERR_INVALID_ARG, "the two buffers must be distinct");
-    if (reinterpret_cast<uintptr_t>(src->p) & 15) return fail(ctx, FWA_ERR_INVALID_ARG, "buffer must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(src->p) & 15)
+        return fail(ctx, FWA_ERR_INVALID_ARG, "buffer must be 16-byte aligned");
 
     const auto t_begin = std::chrono::steady_clock::now();
     USE_DEVICE(ctx);
@@ -372,13 +385,15 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             break;
         case PATH_SMALL:
 #ifdef FWA_LAB
-            if (plan->small_reg != 1) {  // laboratory kernels (A/B): direct 16-point kernels, shuffle exchange, LDS radix 2
+            // laboratory kernels (A/B): direct 16-point kernels, shuffle exchange, LDS radix 2
+            if (plan->small_reg != 1) {
                 if (plan->small_reg && plan->n < 16)
                     e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
                 else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
                     e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
                 else if (plan->small_reg)
-                    e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
+                    e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2,
+                                            st);
                 else
                     e = fwa::launch_lds_small(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
                 break;
@@ -405,13 +420,15 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             // in place at group granularity: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
             const int w = (int)plan->tile_w;
             const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
-            // default: XCD-contiguous tiles + adjacent tiles on the two residents of a CU (bit 2: + 4-8 % for launches that have the
-            // chip to themselves, + 0.6 % with two chains in flight: tile_1m.h xcd_block, profiles/round4/sweep_pair_map_two_chains.jsonl)
+            // default: XCD-contiguous tiles + adjacent tiles on the two residents of a CU (bit 2: + 4-8 % for
+            // launches that have the chip to themselves, + 0.6 % with two chains in flight: tile_1m.h xcd_block,
+            // profiles/round4/sweep_pair_map_two_chains.jsonl)
             const uint32_t swz = plan->xcd_swizzle < 0 ? 5u : (uint32_t)plan->xcd_swizzle;
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 // ring region of this chain: transform i -> slot i (ring_rotate > 1, laboratory: successive groups of a
                 // chain walk through ring_rotate such regions)
-                v2f *slab = plan->ring + ((g / (plan->istreams.empty() ? 1 : plan->istreams.size())) % (uint64_t)plan->ring_rotate) *
+                const uint64_t round = g / (plan->istreams.empty() ? 1 : plan->istreams.size());
+                v2f *slab = plan->ring + (round % (uint64_t)plan->ring_rotate) *
                                              (uint64_t)plan->n_streams * G * N + (uint64_t)c * G * N;
                 hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt, swz, s);
                 if (le != hipSuccess) return le;
@@ -420,16 +437,21 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
         }
 #ifdef FWA_LAB
         case PATH_RING_1M: {
-            if (!plan->ring || !plan->ring_ctl) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
+            if (!plan->ring || !plan->ring_ctl)
+                return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
             const uint64_t slots = (uint64_t)plan->ring_slots < plan->batch ? (uint64_t)plan->ring_slots : plan->batch;
             const uint64_t depth = (uint64_t)plan->depth < slots ? (uint64_t)plan->depth : (slots > 1 ? slots - 1 : 1);
-            e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer[0], plan->ring_ctl, (uint32_t)plan->batch,
-                                    (uint32_t)depth, (uint32_t)(slots > depth ? slots : depth + 1), (uint32_t)plan->wgs, scale, st);
+            e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer[0], plan->ring_ctl,
+                                    (uint32_t)plan->batch,
+                                    (uint32_t)depth, (uint32_t)(slots > depth ? slots : depth + 1),
+                                        (uint32_t)plan->wgs, scale, st);
             break;
         }
         case PATH_TEAM: {
-            if (!plan->ring || !plan->ring_ctl) return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no team slabs (a failed re-tune?)");
-            e = fwa::launch_team(dir, plan->lg, a, out, plan->ring, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, tb.tw_l[1], plan->ring_ctl,
+            if (!plan->ring || !plan->ring_ctl)
+                return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no team slabs (a failed re-tune?)");
+            e = fwa::launch_team(dir, plan->lg, a, out, plan->ring, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, tb.tw_l[1],
+                                 plan->ring_ctl,
                                  (uint32_t)plan->batch, (uint32_t)plan->max_teams, (uint32_t)plan->wgs, scale, st);
             break;
         }
@@ -454,16 +476,20 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 hipError_t le;
                 // k_colsw writes the slab tile-contiguously when the last pass (k_rows32) can read that layout back
                 const bool use_colsw = plan->colsw && fwa::colsw_supported(plan->lf[0]) && plan->lg <= 28;
-                const uint32_t ring_cw = (use_colsw && plan->tile_ring && !three && fwa::rows32_ring_supported(plan->lf[1], fwa::colsw_width(plan->lf[0])))
+                const uint32_t ring_cw = (use_colsw && plan->tile_ring && !three
+                                          && fwa::rows32_ring_supported(plan->lf[1], fwa::colsw_width(plan->lf[0])))
                                              ? fwa::colsw_width(plan->lf[0]) : 0u;
                 if (use_colsw)
-                    le = fwa::launch_colsw(dir, plan->lf[0], true, ring_cw != 0, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1),
+                    le = fwa::launch_colsw(dir, plan->lf[0], true, ring_cw != 0, ta.in, slab, tb.tw_l[0], tb.tw_lo1,
+                                           tb.tw_hi1, (uint32_t)(N / N1),
                                            N, N, (uint32_t)cnt, ta.xcd_swizzle, s);
                 else if (plan->lf[0] > 10)
-                    le = fwa::launch_cols32(dir, plan->lf[0], true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N,
+                    le = fwa::launch_cols32(dir, plan->lf[0], true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1,
+                                            (uint32_t)(N / N1), N,
                                             N, (uint32_t)cnt, ta.xcd_swizzle, s);
                 else if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
-                    le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1, (uint32_t)(N / N1), N, N,
+                    le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1,
+                                            (uint32_t)(N / N1), N, N,
                                             (uint32_t)cnt, ta.xcd_swizzle, s);
                 else
                     le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
@@ -479,8 +505,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                     if (le != hipSuccess) return le;
                 }
                 // pass C: rows of the last axis, cw adjacent k1 per tile
-                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1]) && (plan->rows32 || plan->lf[1] > 10 || ring_cw))
-                    return fwa::launch_rows32(dir, plan->lf[1], slab, out + g * G * N, tb.tw_l[1], (uint32_t)N1, N, N, (uint32_t)cnt,
+                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1])
+                    && (plan->rows32 || plan->lf[1] > 10 || ring_cw))
+                    return fwa::launch_rows32(dir, plan->lf[1], slab, out + g * G * N, tb.tw_l[1], (uint32_t)N1, N, N,
+                                              (uint32_t)cnt,
                                               scale, ta.xcd_swizzle, ring_cw, s);
                 const uint32_t li = three ? 2 : 1;
                 cw = pass_cw(plan, li);

@@ -163,7 +163,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
                 ++ctx->n_ring_allocs;
             }
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::ring_ctl_bytes(p->batch));
-            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e, "hipMalloc(ring control)"); }
+            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e,
+                "hipMalloc(ring control)"); }
         }
         Pipeline old = take_pipeline(p);
         destroy_pipeline_objects(ctx, old, true);
@@ -189,7 +190,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
             if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(team slabs)");
             ++ctx->n_ring_allocs;
             e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::team_ctl_bytes(p->lg, (uint32_t)p->max_teams));
-            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e, "hipMalloc(team control)"); }
+            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e,
+                "hipMalloc(team control)"); }
         }
         Pipeline old = take_pipeline(p);
         destroy_pipeline_objects(ctx, old, true);
@@ -206,7 +208,8 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
     if (n_streams < 1) n_streams = 1;
     if ((uint64_t)n_streams > n_groups && n_groups) n_streams = (int64_t)n_groups;
     Pipeline pl;
-    pl.ring_bytes = p->batch ? (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->n * sizeof(v2f) * (uint64_t)p->ring_rotate : 0;
+    const uint64_t slots = (uint64_t)group * (uint64_t)n_streams * (uint64_t)p->ring_rotate;  // transforms in the ring
+    pl.ring_bytes = p->batch ? slots * (uint64_t)p->n * sizeof(v2f) : 0;
     auto bail = [&](int32_t st) { destroy_pipeline_objects(ctx, pl, false); return st; };
     if (pl.ring_bytes) {
         if (void *pooled = pool_take(ctx, pl.ring_bytes)) {

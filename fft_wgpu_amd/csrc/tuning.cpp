@@ -26,7 +26,11 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
     else if (k == "tile_w") *value = plan->tile_w;
-    else if (k == "xcd_swizzle") *value = plan->xcd_swizzle < 0 ? (plan->path == PATH_TWOPASS_1M ? 5 : (plan->path == PATH_TILED ? (int64_t)tiled_swizzle_default(plan) : 0)) : plan->xcd_swizzle;
+    else if (k == "xcd_swizzle") {
+        const int64_t dflt = plan->path == PATH_TWOPASS_1M ? 5
+                             : (plan->path == PATH_TILED ? (int64_t)tiled_swizzle_default(plan) : 0);
+        *value = plan->xcd_swizzle < 0 ? dflt : plan->xcd_swizzle;
+    }
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;
@@ -49,7 +53,8 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "tile_ring") *value = plan->tile_ring;
     else if (k == "ring_rotate") *value = plan->ring_rotate;
     else if (k == "factors") *value = plan->lf[0] | (plan->lf[1] << 8) | (plan->lf[2] << 16);
-    else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;  // other holders: cache + plans
+    // other holders: cache + plans
+    else if (k == "tables_shared") *value = plan->tb ? (int64_t)plan->tb.use_count() - 1 : 0;
     else if (k == "scratch_bytes")
         *value = (int64_t)plan->ring_bytes + (plan->second_owned ? (int64_t)plan->own_second.bytes : 0) +
                  (plan->ring_ctl ? (int64_t)ctl_bytes(plan) : 0);
@@ -76,19 +81,24 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "group" || k == "streams") {
         if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths (2^20 two-pass, tiled)");
-        if (value < 1 || value > (k == "streams" ? 16 : 4096)) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
+        if (value < 1 || value > (k == "streams" ? 16 : 4096))
+            return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         return build_pipeline(plan, k == "group" ? value : plan->group, k == "streams" ? value : plan->n_streams);
     }
     if (k == "inject_launch_failure") {
         // laboratory: the launch of group `value` fails once (nothing is enqueued for it): the error path of run_groups
-        if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "inject_launch_failure is a laboratory knob (libfft_wgpu_amd_lab.so)");
-        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths");
+        if (!kLab)
+            return fail(ctx, FWA_ERR_UNSUPPORTED,
+                        "inject_launch_failure is a laboratory knob (libfft_wgpu_amd_lab.so)");
+        if (plan->path != PATH_TWOPASS_1M && plan->path != PATH_TILED)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the pipelined paths");
         plan->inject_fail_group = value;
         return FWA_OK;
     }
     if (k == "ring_rotate") {
         if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "ring_rotate is a laboratory knob (libfft_wgpu_amd_lab.so)");
-        if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
+        if (plan->path != PATH_TWOPASS_1M)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
         if (value < 1 || value > 64) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         const int64_t old = plan->ring_rotate;
         plan->ring_rotate = value;
@@ -97,9 +107,11 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         return st;
     }
     if (k == "tile_w") {
-        if (plan->path != PATH_TWOPASS_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
+        if (plan->path != PATH_TWOPASS_1M)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
         if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "tile_w is 16 or 32");
-        if (value == 32 && !kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "tile_w = 32 is a laboratory variant (libfft_wgpu_amd_lab.so)");
+        if (value == 32 && !kLab)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "tile_w = 32 is a laboratory variant (libfft_wgpu_amd_lab.so)");
         plan->tile_w = value;
         return FWA_OK;
     }
@@ -113,7 +125,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             uint32_t ts = 0, th = 0;
             size_t lds = 0;
             fwa::team_geometry(plan->lg, &ts, &th, &lds);
-            if (value < 8 * (int64_t)ts) return fail(ctx, FWA_ERR_INVALID_ARG, "wgs must be at least 8 x the team size");
+            if (value < 8 * (int64_t)ts)
+                return fail(ctx, FWA_ERR_INVALID_ARG, "wgs must be at least 8 x the team size");
             plan->wgs = value;
             return FWA_OK;
         }
@@ -123,12 +136,16 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
 #endif
     if (k == "max_teams" || k == "depth" || k == "ring_slots" || k == "wgs") {
         if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "key belongs to a laboratory path (libfft_wgpu_amd_lab.so)");
-        if (plan->path != PATH_RING_1M) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
+        if (plan->path != PATH_RING_1M)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
         if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
         if (k == "wgs") { plan->wgs = value; return FWA_OK; }
         const int64_t d = k == "depth" ? value : plan->depth, r = k == "ring_slots" ? value : plan->ring_slots;
         if (k == "depth") { plan->depth = d; if (r < d + 1) plan->ring_slots = d + 1; }
-        else { if (r < plan->depth + 1) return fail(ctx, FWA_ERR_INVALID_ARG, "ring_slots must exceed depth"); plan->ring_slots = r; }
+        else {
+            if (r < plan->depth + 1) return fail(ctx, FWA_ERR_INVALID_ARG, "ring_slots must exceed depth");
+            plan->ring_slots = r;
+        }
         return build_pipeline(plan, 0, 0);
     }
     if (k == "xcd_swizzle") {
@@ -148,10 +165,13 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         for (uint32_t i = 0; i < nf; ++i) {
             // 2048: as the first factor (k_cols32); 2048 / 4096: as the second of two (k_rows32); n <= 2^28
             const uint32_t top = plan->lg > 28 ? 10u : (i == 0 ? 11u : ((nf == 2 && i == 1) ? 12u : 10u));
-            if (f[i] < 6 || f[i] > top) return fail(ctx, FWA_ERR_INVALID_ARG, "every factor must be 2^6..2^10 (2^11: first; 2^11, 2^12: second of two)");
+            if (f[i] < 6 || f[i] > top)
+                return fail(ctx, FWA_ERR_INVALID_ARG,
+                            "every factor must be 2^6..2^10 (2^11: first; 2^11, 2^12: second of two)");
             sum += f[i];
         }
-        if (sum != plan->lg || (value >> 24)) return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");
+        if (sum != plan->lg || (value >> 24))
+            return fail(ctx, FWA_ERR_INVALID_ARG, "factors do not multiply to fft_len");
         const int64_t old_path = plan->path;
         uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
         plan->path = PATH_TILED;
@@ -162,20 +182,24 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     }
     if (k == "p1_gen" || k == "rows32" || k == "colsw" || k == "tile_ring") {
         if (plan->path != PATH_TILED) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to tiled plans");
-        (k == "p1_gen" ? plan->p1_gen : k == "rows32" ? plan->rows32 : k == "colsw" ? plan->colsw : plan->tile_ring) = value != 0;
+        int64_t &flag = k == "p1_gen" ? plan->p1_gen : k == "rows32" ? plan->rows32
+                        : k == "colsw" ? plan->colsw : plan->tile_ring;
+        flag = value != 0;
         return FWA_OK;
     }
     if (k == "wave") {
-        if (plan->path != PATH_SMALL || plan->n != 512) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n = 512");
+        if (plan->path != PATH_SMALL || plan->n != 512)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n = 512");
         plan->wave = value != 0;
         return FWA_OK;
     }
     if (k == "small_reg") {
         if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 32768");
-        if (value != 1 && !kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "small_reg != 1 selects laboratory kernels (libfft_wgpu_amd_lab.so)");
+        if (value != 1 && !kLab)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "small_reg != 1 selects laboratory kernels (libfft_wgpu_amd_lab.so)");
         if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
         // 1: k_chunk (4 .. 256) and k_small32 (from 512), the default; 3: the direct-addressing kernels k_tiny16 /
-        // k_small16 up to 4096 (A/B); 2: as 3 with the wavefront-shuffle exchange at n = 32/64/128; 0: LDS radix-2 kernel
+        // k_small16 up to 4096 (A/B); 2: as 3 with the wavefront-shuffle exchange at n = 32/64/128; 0: LDS radix 2
         plan->small_reg = (value >= 0 && value <= 3) ? value : 1;
         return FWA_OK;
     }
@@ -184,13 +208,15 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (value == plan->path) return FWA_OK;
         if ((value == PATH_RING_1M || value == PATH_TEAM) && !kLab)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "paths 5 and 8 are laboratory paths (libfft_wgpu_amd_lab.so)");
-        if ((value == PATH_RING_1M || value == PATH_TWOPASS_1M) && (plan->path == PATH_RING_1M || plan->path == PATH_TWOPASS_1M)) {
+        if ((value == PATH_RING_1M || value == PATH_TWOPASS_1M)
+            && (plan->path == PATH_RING_1M || plan->path == PATH_TWOPASS_1M)) {
             // the two forms of the 2^20 pipeline: per-group launches with a large ring, or one persistent launch
             const int64_t old = plan->path;
             plan->path = value;
             const int32_t st = setup_path(plan);
             if (st) plan->path = old;
-            if (!st && value == PATH_TWOPASS_1M && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
+            if (!st && value == PATH_TWOPASS_1M
+                && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
             return st;
         }
         if ((value == PATH_TEAM || value == PATH_TILED) && (plan->path == PATH_TEAM || plan->path == PATH_TILED)) {
@@ -201,11 +227,14 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             const int64_t old = plan->path;
             uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
             plan->path = value;
-            if (value == PATH_TEAM) { plan->lf[0] = plan->lg / 2; plan->lf[1] = plan->lg - plan->lf[0]; plan->lf[2] = 0; }
+            if (value == PATH_TEAM) {
+                plan->lf[0] = plan->lg / 2; plan->lf[1] = plan->lg - plan->lf[0]; plan->lf[2] = 0;
+            }
             else { bool cw = false; (void)choose_path(plan->n, plan->batch, plan->lf, &cw); plan->colsw = cw; }
             const int32_t st = setup_path(plan);
             if (st) { plan->path = old; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
-            if (!st && value == PATH_TILED && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
+            if (!st && value == PATH_TILED
+                && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
             return st;
         }
         if (value == PATH_R2_GLOBAL && plan->n >= 2) {
@@ -227,7 +256,8 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             plan->path = PATH_R2_GLOBAL;
             return FWA_OK;
         }
-        return fail(ctx, FWA_ERR_UNSUPPORTED, "only path = 2 (the literal radix-2 recurrence) or, at n = 2^20, 1 / 5 can be set");
+        return fail(ctx, FWA_ERR_UNSUPPORTED,
+                    "only path = 2 (the literal radix-2 recurrence) or, at n = 2^20, 1 / 5 can be set");
     }
     return fail(ctx, FWA_ERR_INVALID_ARG, "unknown key: " + k);
 }
