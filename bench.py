@@ -431,22 +431,28 @@ def main():
             else:
                 finished = threading.Event()
 
-                def give_up():   # the exchange hangs: the timed figures are still good -- print them and leave
-                    if finished.is_set():
-                        return
+                def leave(what):
+                    """The exchange failed or hangs on this rank: the other ranks may be parked in it for good, so no
+                    further collective is safe.  The timed figures are complete: rank 0 prints the line with the failure
+                    in `movement`, every rank leaves with status 0 (the measurement stands; the failure is in the line)."""
                     if rank == 0:
-                        print(json.dumps(build_line({"error": f"fwa_comm scatter / gather did not finish in "
-                                                              f"{MOVE_TIMEOUT_S} s; the line is complete without it"})), flush=True)
+                        print(json.dumps(build_line({"error": what})), flush=True)
                     else:
-                        time.sleep(3.0)   # rank 0 prints first; a launcher tears the job down at the first exit
-                    os._exit(0)           # status 0 on every rank: the failure is in the line, the measurement stands
+                        time.sleep(3.0)   # rank 0 prints first; a launcher may tear the job down at the first exit
+                    os._exit(0)
+
+                def give_up():
+                    if not finished.is_set():
+                        leave(f"fwa_comm scatter / gather did not finish in {MOVE_TIMEOUT_S} s; the line is complete without it")
                 dog = threading.Timer(MOVE_TIMEOUT_S, give_up)
                 dog.daemon = True
                 dog.start()
                 try:
                     movement = move_slabs(fw, dist, torch, dev, enc, buf, n, mt, rank, world, coll_dev)
-                except Exception as e:   # a status code from the library: report it, keep the line
-                    movement = {"error": f"{type(e).__name__}: {e}"}
+                except Exception as e:   # a status code from the library on THIS rank
+                    finished.set()
+                    dog.cancel()
+                    leave(f"{type(e).__name__}: {e}")
                 finished.set()
                 dog.cancel()
 
@@ -463,6 +469,8 @@ def move_slabs(fw, dist, torch, dev, enc, buf, n, mt, rank, world, coll_dev):
     (its own slab is a local copy) divided by the slowest rank's time.  Buffers are views of the benchmark buffer:
     on rank 0 the first world * mt transforms are the full batch and the next mt its slab; elsewhere the first mt."""
     from fft_wgpu_amd import sharding
+    if os.environ.get("FWA_BENCH_FAIL_MOVEMENT") == str(rank):    # test knob: the library refuses on this rank
+        raise RuntimeError("movement failure on request (FWA_BENCH_FAIL_MOVEMENT)")
     tb = 8 * n
     uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
     if rank == 0:

@@ -134,3 +134,16 @@ def test_distributed_leg_on_rccl_with_the_movement_leg():
     assert "error" not in mv and "skipped" not in mv, mv
     assert mv["transforms_per_rank"] == 256 and mv["bytes_per_rank"] == 256 << 23
     assert mv["scatter_ms"] > 0 and mv["gather_ms"] > 0 and mv["scatter_GBps"] is None   # nothing leaves rank 0 at world 1
+
+
+def test_a_failing_movement_leg_keeps_the_measured_line():
+    """The slab-movement leg fails on a rank (FWA_BENCH_FAIL_MOVEMENT): no further collective is safe, so the rank prints the
+    complete line with the failure recorded in `movement` and leaves with status 0 -- the timed figures stand."""
+    env = _clean_env(FWA_BENCH_FORCE_DIST="1", FWA_BENCH_FAIL_MOVEMENT="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                     RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "256",
+                        "--spread", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    line = _one_line(r.stdout)
+    assert "on request" in line["movement"]["error"] and np.isfinite(line["value"]) and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["steps"] == 2
