@@ -15,7 +15,7 @@ status, so a dead rank never leaves the others parked in a barrier.  It refuses 
 devices than --gpus.
 
 Order of one run: rank 0 times the CPU baseline first (the oracle's restatement of the reference algorithm on
-the host cores, ~12 s, nothing on the GPU yet; the other ranks wait in the rendezvous, timeout 120 s), then the
+the host cores, ~12 s, nothing on the GPU yet; the other ranks wait in the rendezvous, timeout 300 s), then the
 GPU phase -- warm-up, the K timed steps, the stream-ceiling calibration and a 100-exec spread leg on rank 0 (HIP
 events only, not part of `value`), and for N > 1 the slab-movement leg (below).  The line carries "gpu_phase_s".
 
@@ -51,9 +51,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 16      # one 8-B read + one 8-B write per complex sample
 CHUNK = 8                       # steps between input regenerations (2^-40 * 2^(10*8) stays finite)
-RENDEZVOUS_TIMEOUT_S = 120      # init_process_group / collectives: a missing rank is an error after this long
+RENDEZVOUS_TIMEOUT_S = 300      # init_process_group / collectives: a missing rank is an error after this long.  Generous on
+                                # purpose: on a cold box the ranks' first `import torch` takes 1-2 minutes and rank 0 spends
+                                # 12 s more on the CPU baseline; a rank that DIES is caught at once by the launcher (torchrun,
+                                # or supervise() below), not by this timeout
 MOVE_TRANSFORMS = 256           # slab moved per rank by the movement leg (2 GiB at N = 2^20)
-MOVE_TIMEOUT_S = 90
+MOVE_TIMEOUT_S = 120
 
 
 def usable_cores():

@@ -176,6 +176,7 @@ class ShardedBatch:
         self._owns_devices = devices is None
         self.threads = threads
         self._pool = None
+        self._many_launches = None
         self.devices = list(devices) if devices is not None else [Device(o, lab=lab) for o in ordinals]
         self.queues = [Queue(d) for d in self.devices]
         self.encoders = [d.create_command_encoder() for d in self.devices]
@@ -197,7 +198,9 @@ class ShardedBatch:
     def _threaded(self):
         if self.threads is not None:
             return bool(self.threads) and len(self.plans) > 1
-        return len(self.plans) > 1 and max(p.get("launches_per_exec") for p in self.plans) >= self.THREAD_MIN_LAUNCHES
+        if self._many_launches is None:      # the plans do not change after construction
+            self._many_launches = max(p.get("launches_per_exec") for p in self.plans) >= self.THREAD_MIN_LAUNCHES
+        return len(self.plans) > 1 and self._many_launches
 
     def proc(self):
         """Enqueue the transform of every slab on its device's encoder; returns the list of result buffers.  Returns when

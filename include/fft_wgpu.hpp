@@ -353,8 +353,13 @@ public:
     {
         const size_t n = dev_.size();
         bool threaded = enqueue_ == Enqueue::threaded;
-        if (enqueue_ == Enqueue::automatic)
-            for (size_t i = 0; i < n && !threaded; ++i) threaded = plan_[i]->get("launches_per_exec") >= thread_min_launches;
+        if (enqueue_ == Enqueue::automatic) {
+            if (many_launches_ < 0) {   // the plans do not change after construction
+                many_launches_ = 0;
+                for (size_t i = 0; i < n; ++i) many_launches_ |= plan_[i]->get("launches_per_exec") >= thread_min_launches;
+            }
+            threaded = many_launches_ != 0;
+        }
         if (n < 2 || !threaded) {
             for (size_t i = 0; i < n; ++i) result_[i] = &plan_[i]->proc(*enc_[i]);
             return;
@@ -410,6 +415,7 @@ private:
     std::vector<std::unique_ptr<PlanT>> plan_;
     std::vector<Buffer *> result_;
     Enqueue enqueue_ = Enqueue::automatic;
+    int many_launches_ = -1;
 };
 
 // One rank of a slab communicator over RCCL (fwa_comm_*), for hosts that run ONE PROCESS PER GPU and do not hold each other's
