@@ -257,7 +257,9 @@ def main():
             dist_barrier()
 
     regen()
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        if w and w % CHUNK == 0:
+            regen()            # as in the timed loop: never more than CHUNK in-place transforms on one fill (x 2^10 each)
         plan.proc(enc)
     barrier()
 
