@@ -630,6 +630,44 @@ def test_config_c3_full_size_sampled(gpu, oracle):
         assert mx <= REL_TOL
 
 
+@pytest.mark.parametrize("lg", [9, 6, 12])
+def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg):
+    """The one-launch kernels at C3's footprint (2^32 samples = 32 GiB: byte offsets beyond 2^32, half a million workgroups):
+    k_wave512 (n = 512: 2^23 transforms; the result lands in the plan's second buffer), k_chunk (64) and k_small32 with its
+    look-ups ahead of the data (4096).  Sampled transforms -- the first, the last, some in between, one beyond every 4-GiB
+    boundary -- against the fp64 DFT of the generator's output, then the scaled inverse restores the input at full size."""
+    fw, dev, queue = gpu
+    n, batch = 1 << lg, 1 << (32 - lg)
+    if dev.info()["hbm_bytes"] < 80 * 2 ** 30:
+        pytest.skip("needs 32 GiB buffers")
+    buf = dev.create_buffer(n * batch * 8)
+    enc = dev.create_command_encoder()
+    dev.fill_synthetic(buf, n, encoder=enc)
+    plan = fw.Forward(dev, queue, buf, n)
+    out = plan.proc(enc)
+    enc.synchronize()
+    assert plan.get("path") == 0 and plan.get("launches_per_exec") == 1 and (out is buf) == (lg % 2 == 0)
+    per_4g = (1 << 32) // (n * 8)                        # transforms per 4 GiB
+    rng = np.random.default_rng(lg)
+    sample = sorted({0, batch - 1, 1, batch // 2 + 3} | {k * per_4g + int(rng.integers(0, per_4g)) for k in range(8)})
+    for t in sample:
+        y = out.map_read(offset=t * n * 8, size=n * 8, stream=enc)
+        x = oracle.gen_input(n, 1, first_transform=t)
+        mx, l2 = oracle.compare(y, oracle.dft_f64(x, n, -1))
+        assert mx <= REL_TOL and l2 <= REL_TOL, (lg, t, mx, l2)
+    inv = fw.Inverse(dev, queue, out, n)
+    back = inv.proc(enc)
+    enc.synchronize()
+    for t in (sample[0], sample[len(sample) // 2], sample[-1]):
+        z = back.map_read(offset=t * n * 8, size=n * 8, stream=enc)
+        x = oracle.gen_input(n, 1, first_transform=t)
+        mx, _ = oracle.compare(z, x.astype(np.complex128))
+        assert mx <= REL_TOL, (lg, t, mx)
+    inv.destroy()
+    plan.destroy()
+    buf.destroy()
+
+
 # ---- the reference's benchmark loop, pipelined over two streams with pinned staging (SURVEY 8(f) rank 2) ----
 @pytest.mark.parametrize("slots", [2, 3])
 def test_host_transfer_pipeline_matches_oracle(gpu, oracle, slots):
