@@ -20,7 +20,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import fft_wgpu_amd as fw  # noqa: E402
-import oracle  # noqa: E402  (generator only)
 
 
 def main():
@@ -46,7 +45,11 @@ def main():
             batch = 1 << max(0, args.total_lg - lg)
         # identical bits on a small batch
         small = min(batch, max(1, (1 << 22) >> lg) + 1)
-        x = oracle.gen_input(n, small, first_transform=5)
+        d0, _, e0 = ctx[libs[0][0]]
+        g = d0.create_buffer(8 * n * small)
+        d0.fill_synthetic(g, n, first_transform=5, encoder=e0)
+        x = g.map_read(stream=e0)
+        g.destroy()
         outs = {}
         for name, (dev, queue, enc) in ctx.items():
             b = dev.create_buffer(x.nbytes)
