@@ -60,6 +60,34 @@ __device__ __forceinline__ uint32_t xcd_map(uint32_t swizzle)
     return (b & 7u) * per + i;
 }
 
+// Workgroup -> chunk index of the one-launch (streaming) kernels k_chunk, k_small32, k_scale, k_copy (round 5).  Blocks are
+// dealt round-robin over the 8 XCDs; with the plain map XCD x works on every eighth 64-KiB chunk of one moving window.  Map 5
+// (xcd_map bits 0 + 2: every XCD a contiguous run of chunks, and the i-th and (i + 32)-th workgroup of an XCD -- two residents
+// of one CU -- on ADJACENT chunks) is worth + 1.3 ... + 7.6 % at every size from 2 to 32768 and + 2 ... + 8 % on normalize at
+// the 32-GiB footprint, one library per map side by side in one process (tools/ab_libs.py,
+// profiles/round5/ab_one_launch_block_map.jsonl; a pure streaming pass: + 1.6-2.4 %, probe_stream_shapes_32GiB.txt).  Bit 0
+// alone LOSES up to 11 % at some sizes, four or eight adjacent chunks per CU lose 1-9 %
+// (ab_one_launch_block_map_pairs_quads_octs_16GiB.jsonl).  n = 512 (k_wave512) is the exception: - 1 ... - 2 % at 32 GiB,
+// so it keeps blockIdx.x.  Results do not depend on the map.
+#ifndef FWA_ONE_LAUNCH_MAP
+#define FWA_ONE_LAUNCH_MAP 5
+#endif
+__device__ __forceinline__ uint32_t one_launch_block()
+{
+    if constexpr (FWA_ONE_LAUNCH_MAP == 0) return blockIdx.x;
+    // the map covers the largest prefix of the grid that is whole runs of 64 workgroups per XCD (a multiple of 512 blocks:
+    // bit 0 without bit 2 is the map that loses); the ragged remainder keeps the plain map
+    const uint32_t b = blockIdx.x, whole = gridDim.x & ~511u;
+    if (b >= whole) return b;
+    const uint32_t per = whole >> 3;
+    uint32_t i = b >> 3;
+    if constexpr ((FWA_ONE_LAUNCH_MAP & 4) != 0) {
+        const uint32_t r = i & 63u;
+        i = (i & ~63u) + (((r & 31u) << 1) | (r >> 5));
+    }
+    return (b & 7u) * per + i;
+}
+
 template <int N>
 __device__ __forceinline__ v2f tw_lookup(const v2f *__restrict__ tw, uint32_t e)  // W_N^e, 0 <= e < N
 {

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, (LGN >= 6 ? 3 : 4)) void k_chunk(const v2f *__
     constexpr bool EARLY = LGN >= 6;   // store a half as soon as it is done (register pressure: see below)
     __shared__ v2f lds_all[HALF + HALF / 16];
     const uint32_t tid = threadIdx.x;
-    const uint64_t e0 = (uint64_t)blockIdx.x * CH;
+    const uint64_t e0 = (uint64_t)one_launch_block() * CH;
     const uint64_t left = n_samples - e0;
     const uint32_t valid = left < CH ? (uint32_t)left * 8u : CH * 8u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + e0), 0, valid, 0x00020000);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_scale(const v2f *__restrict__ a, v2f *_
                                                float scale)
 {
     constexpr uint32_t CH = 8192;  // samples per workgroup
-    const uint64_t e0 = (uint64_t)blockIdx.x * CH;
+    const uint64_t e0 = (uint64_t)one_launch_block() * CH;
     const uint64_t left = n_samples - e0;
     const uint32_t valid = left < CH ? (uint32_t)left * 8u : CH * 8u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(a + e0), 0, valid, 0x00020000);
@@ -130,7 +130,7 @@ hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st)
 __global__ __launch_bounds__(256) void k_copy(const char *__restrict__ a, char *__restrict__ b, uint64_t n_chunks)
 {
     constexpr uint32_t CHUNK = 65536, U = 32;
-    const uint64_t c = blockIdx.x;
+    const uint64_t c = one_launch_block();
     if (c >= n_chunks) return;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a) + c * CHUNK, 0, CHUNK, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + c * CHUNK, 0, CHUNK, 0x00020000);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__((LGN <= 13 ? 256 : (1 << (LGN - 5))), 4) void k_sma
                                                                                     const v2f *__restrict__ tw,
                                                                                     uint64_t batch, float scale)
 {
-    small32_body<LGN, DIR, PREFETCH>(src, dst, tw, batch, scale, blockIdx.x, threadIdx.x);
+    small32_body<LGN, DIR, PREFETCH>(src, dst, tw, batch, scale, one_launch_block(), threadIdx.x);
 }
 
 static uint32_t small32_xpw(uint32_t lg_n) { return lg_n <= 13 ? 256u / (1u << (lg_n - 5)) : 1u; }  // lg_n >= 6

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
 
     // the descriptor ends with the data: lanes of a ragged last chunk read zeros, their stores are dropped
-    const uint64_t e0 = (uint64_t)blockIdx.x * CH;
+    const uint64_t e0 = (uint64_t)blockIdx.x * CH;   // plain map: the pair map of the other one-launch kernels loses 1-2 % here
     const uint64_t left = n_samples - e0;
     const uint32_t valid = left < CH ? (uint32_t)left * 8u : CH * 8u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(src + e0), 0, valid, 0x00020000);

@@ -37,6 +37,7 @@ def main():
         dev = fw.Device(0, lab=os.path.abspath(path))
         ctx[name] = (dev, fw.Queue(dev), dev.create_command_encoder())
     blk = 256 << 20
+    two = args.kind in ("Onlyinverse", "Normalize")     # plan kinds with a caller-supplied second buffer
     for shape in args.shapes.split(","):
         lat = "x" in shape
         lg, batch = (int(t) for t in shape.split("x")) if lat else (int(shape), 0)
@@ -54,17 +55,24 @@ def main():
         for name, (dev, queue, enc) in ctx.items():
             b = dev.create_buffer(x.nbytes)
             queue.write_buffer(b, 0, x)
-            p = getattr(fw, args.kind)(dev, queue, b, n)
+            b2 = dev.create_buffer(x.nbytes) if two else None
+            if two and n.bit_length() % 2 == 0:   # odd log2 n: Normalize reads the SECOND buffer (processor.rs:433-439)
+                queue.write_buffer(b2, 0, x)
+            p = getattr(fw, args.kind)(dev, queue, b, b2, n) if two else getattr(fw, args.kind)(dev, queue, b, n)
             outs[name] = p.proc(enc).map_read(stream=enc)
             p.destroy()
             b.destroy()
+            if b2 is not None:
+                b2.destroy()
         ref = outs[libs[0][0]]
         same = {name: bool(np.array_equal(ref.view(np.uint32), y.view(np.uint32))) for name, y in outs.items()}
         worst = {name: float(np.abs(y - ref).max() / np.abs(ref).max()) for name, y in outs.items()}
-        plans, bufs, blockers = {}, {}, {}
+        plans, bufs, blockers, seconds = {}, {}, {}, {}
         for name, (dev, queue, enc) in ctx.items():
             bufs[name] = dev.create_buffer(8 * n * batch)
-            plans[name] = getattr(fw, args.kind)(dev, queue, bufs[name], n)
+            seconds[name] = dev.create_buffer(8 * n * batch) if two else None
+            plans[name] = (getattr(fw, args.kind)(dev, queue, bufs[name], seconds[name], n) if two
+                           else getattr(fw, args.kind)(dev, queue, bufs[name], n))
             if lat:
                 bl = dev.create_buffer(2 * blk)
                 blockers[name] = (bl, dev.wrap_buffer(bl.device_ptr, blk), dev.wrap_buffer(bl.device_ptr + blk, blk))
@@ -99,6 +107,8 @@ def main():
         for name in ctx:
             plans[name].destroy()
             bufs[name].destroy()
+            if seconds[name] is not None:
+                seconds[name].destroy()
             if lat:
                 for h in blockers[name][1:] + blockers[name][:1]:
                     h.destroy()
