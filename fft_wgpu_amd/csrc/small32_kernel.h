@@ -22,11 +22,12 @@ namespace fwa {
 // latency between the last data load landing and the exchange; they depend on the thread index only, so they can go out
 // BEFORE the data loads (bit 0: the twiddles of stage 0, bit 1: those of stage 1 of the three-stage sizes) or right BEHIND
 // them, before the wait for the data (bits 2, 3).  Per size, at the 32-GiB footprint, interleaved, bit-identical results
-// (tools/small32_prefetch_probe.hip, profiles/round5/probe_small32_twiddle_prefetch.jsonl): 2^10 0.775 -> 0.790 (behind),
-// 2^11 0.740 -> 0.790 (both stages, before), 2^12 0.705 -> 0.738 (behind), 2^13 0.717 -> 0.739 (behind); where the extra
-// live registers spill (stage 1 at 2^12, 2^14, 2^15) or the schedule changes for the worse (2^14: - 1 ... - 9 %, 2^15:
-// - 2 ... - 4 %) the look-ups stay at the point of use.
-constexpr int small32_prefetch_default(int lgn) { return lgn == 11 ? 3 : (lgn == 10 || lgn == 12 || lgn == 13) ? 4 : 0; }
+// (tools/small32_prefetch_probe.hip).  With the plain block -> chunk map (profiles/round5/probe_small32_twiddle_prefetch.jsonl):
+// 2^10 0.775 -> 0.790, 2^11 0.740 -> 0.790, 2^12 0.705 -> 0.738, 2^13 0.717 -> 0.739.  With the pair map of one_launch_block
+// (device_common.h), which came later and lifts the point-of-use form by more (probe_small32_twiddle_prefetch_pair_map.jsonl):
+// 2^10 0.807 -> 0.814 (behind), 2^11 0.806 -> 0.807 (both stages, before), 2^12 0.774 -> 0.778 (behind) -- kept -- and 2^13
+// 0.787 -> 0.758: back at the point of use, as 2^14 / 2^15 (spills from stage 1 on, or a worse schedule: - 1 ... - 9 %).
+constexpr int small32_prefetch_default(int lgn) { return lgn == 11 ? 3 : (lgn == 10 || lgn == 12) ? 4 : 0; }
 
 template <int LGN, int DIR, int PREFETCH = small32_prefetch_default(LGN)>
 __device__ __forceinline__ void small32_body(const v2f *__restrict__ src, v2f *__restrict__ dst, const v2f *__restrict__ tw,

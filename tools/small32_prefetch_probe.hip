@@ -99,6 +99,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     int rc = 0;
+    if (!rc) rc = run<9>(a, b, rounds, st, e0, e1);
     if (!rc) rc = run<10>(a, b, rounds, st, e0, e1);
     if (!rc) rc = run<11>(a, b, rounds, st, e0, e1);
     if (!rc) rc = run<12>(a, b, rounds, st, e0, e1);
