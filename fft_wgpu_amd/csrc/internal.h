@@ -123,30 +123,28 @@ struct fwa_plan {
     int64_t group = 16;            // transforms per launch
     int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
     int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
-    // XCD-aware block -> tile mapping: -1 = per-path default (on for the 2^20 two-pass path:
+    // XCD-aware block -> tile mapping (xcd_map bits): -1 = per-path, per-size default (5 on the 2^20 two-pass path;
+    // tiled plans: tiled_swizzle_default, plan.cpp)
     int64_t xcd_swizzle = -1;
-                                   // +2 %; off for the tiled path: 1-5 % faster without,
-                                   // profiles/round2/sweep_xcd_swizzle.jsonl)
-    // two-pass tiled plans with a 512..2048-point second factor: 1 = k_rows32 as last pass
-    int64_t rows32 = 1;
+    int64_t rows32 = 1;            // two-pass tiled plans with a 512..4096-point second factor: 1 = k_rows32 last
     int64_t p1_gen = 1;            // tiled plans with first factor 1024: 1 = k_p1_gen as pass A, 0 = k_tile
-    // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) as pass A, 0 = k_tile
-    int64_t colsw = 0;
+    int64_t colsw = 0;             // tiled plans with first factor 256 / 512: 1 = k_colsw (64 / 32-column tiles) first
     int64_t tile_ring = 1;         // k_colsw + k_rows32: 1 = tile-contiguous ring slab, 0 = matrix layout
-    // laboratory: the ring is this many times larger and the groups rotate through it (same
+    // laboratory: the ring is this many times larger and the groups rotate through it (same launches, larger cache
+    // footprint: prices what the Infinity Cache gives the ring)
     int64_t ring_rotate = 1;
-                                   // launches, larger cache footprint: prices what the Infinity Cache gives the ring)
-    // n = 512: 1 = k_wave512 (wave-private, a wave's four transforms one at a time: 0.78 of the
-    int64_t wave = 1;
-                                   // roofline against 0.71, profiles/round5/ab_wave512.jsonl), 0 = k_small32<9>
+    // n = 512: 0 = k_small32<9>, 1 = k_wave512 (wave-private, a wave's four transforms one at a time).  With the plain
+    // block map 0.71 against 0.78 (profiles/round5/ab_wave512.jsonl); under the pair map of one_launch_block
+    // k_small32<9> reaches 0.785-0.825 against 0.766-0.789 over five boxes (ab_wave512_after_pair_map.jsonl): the default
+    int64_t wave = 0;
     // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     int64_t small_reg = 1;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
     hipEvent_t ev_fork = nullptr;
-    // the caller's stream of the last exec that used the ring: fwa_plan_destroy waits for the
+    // the caller's stream of the last exec that used the ring: fwa_plan_destroy waits for the work enqueued there (an
+    // event per exec would cost 4-5 us on the 1-3-launch latency shapes)
     hipStream_t last_stream = nullptr;
-    // work enqueued there (an event per exec would cost 4-5 us on the 1-3-launch latency shapes)
     bool ran_on_stream = false;
     // persistent 2^20 pipeline (PATH_RING_1M)
     uint32_t *ring_ctl = nullptr;  // ticket, error word, per-transform hand-off counters
@@ -162,7 +160,6 @@ struct fwa_plan {
 namespace fwa_int {
 
 // ---- errors (ctx_streams.cpp): record the message on the context (or thread-locally without one), return the status
-//   ----
 int32_t fail(const fwa_ctx *ctx, int32_t status, const std::string &msg);
 int32_t fail_hip(const fwa_ctx *ctx, hipError_t e, const char *what, int32_t status = FWA_ERR_HIP);
 const char *thread_error_string();

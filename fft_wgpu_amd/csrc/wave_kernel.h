@@ -1,5 +1,7 @@
 // wave_kernel.h -- k_wave512, the wave-private one-launch kernel for n = 512, as a template (kernels_wave.hip: the library's
-// instantiations and launcher; tools/wave_probe.hip: knock-out and alternative variants for timing).
+// instantiations and launcher; tools/wave_probe.hip: knock-out and alternative variants for timing).  Plan key "wave" = 1
+// selects it; the default at 512 is k_small32<9>, which has been level or ahead since the one-launch kernels got their block
+// map (device_common.h: one_launch_block; profiles/round5/ab_wave512_after_pair_map.jsonl: 0.785-0.825 against 0.766-0.789).
 //
 // One 256-thread workgroup per 64-KiB-aligned chunk, every WAVE walks its own 16 KiB = four whole transforms front to back
 // with 32 loads of 512 contiguous bytes (the streaming shape of DESIGN.md 2.1) and never addresses global memory any other

@@ -266,7 +266,7 @@ def test_n1m_matches_literal_recurrence(gpu, oracle):
 _DISTANCE_CASES = [
     # (n, batch, expected (path, factors, launches per exec), kernels)
     (256, 40, (0, None, 1), "k_chunk"),
-    (512, 20, (0, None, 1), "k_wave512 (the reference's own length, examples/basic.rs:32)"),
+    (512, 20, (0, None, 1), "k_small32<9> (the reference's own length, examples/basic.rs:32)"),
     (1024, 1, (0, None, 1), "k_small32<10>: config C1's shape"),
     (1 << 13, 6, (0, None, 1), "k_small32<13>: two exchanges"),
     (1 << 15, 3, (0, None, 1), "k_small32<15>: 1024 threads"),
@@ -545,8 +545,8 @@ def test_onlyinverse_plus_normalize_equals_inverse(gpu, oracle):
 
 @pytest.mark.parametrize("batch", [1, 3, 4, 15, 16, 17, 61, 4099])
 def test_n512_wave_private_kernel_and_its_alternative(gpu, oracle, batch):
-    """n = 512, the reference's own length (examples/basic.rs:32,66): the default kernel k_wave512 (every wave walks 16 KiB =
-    four transforms and takes them one at a time: wave_kernel.h) and the alternative k_small32<9> ("wave" = 0), all three
+    """n = 512, the reference's own length (examples/basic.rs:32,66): the default kernel k_small32<9> ("wave" = 0) and the
+    alternative k_wave512 ("wave" = 1: every wave walks 16 KiB = four transforms and takes them one at a time), all three
     transforming plans, against the fp64 DFT; batches that leave a wave (4 transforms), a workgroup (16) and the last chunk
     ragged; the result lands in the second buffer (odd log2 n, processor.rs:153-157); the two kernels agree to rounding."""
     fw, dev, queue = gpu
@@ -630,11 +630,11 @@ def test_config_c3_full_size_sampled(gpu, oracle):
         assert mx <= REL_TOL
 
 
-@pytest.mark.parametrize("lg", [9, 6, 12])
-def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg):
-    """The one-launch kernels at C3's footprint (2^32 samples = 32 GiB: byte offsets beyond 2^32, half a million workgroups):
-    k_wave512 (n = 512: 2^23 transforms; the result lands in the plan's second buffer), k_chunk (64) and k_small32 with its
-    look-ups ahead of the data (4096).  Sampled transforms -- the first, the last, some in between, one beyond every 4-GiB
+@pytest.mark.parametrize("lg,wave", [(9, 0), (9, 1), (6, None), (12, None)])
+def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg, wave):
+    """The one-launch kernels at C3's footprint (2^32 samples = 32 GiB: byte offsets beyond 2^32, half a million workgroups,
+    the pair block map over the whole grid): n = 512 (2^23 transforms; k_small32<9> and, with "wave" = 1, k_wave512; the result
+    lands in the plan's second buffer), k_chunk (64) and k_small32 with its look-ups ahead of the data (4096).  Sampled transforms -- the first, the last, some in between, one beyond every 4-GiB
     boundary -- against the fp64 DFT of the generator's output, then the scaled inverse restores the input at full size."""
     fw, dev, queue = gpu
     n, batch = 1 << lg, 1 << (32 - lg)
@@ -644,6 +644,8 @@ def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg):
     enc = dev.create_command_encoder()
     dev.fill_synthetic(buf, n, encoder=enc)
     plan = fw.Forward(dev, queue, buf, n)
+    if wave is not None:
+        plan.set("wave", wave)
     out = plan.proc(enc)
     enc.synchronize()
     assert plan.get("path") == 0 and plan.get("launches_per_exec") == 1 and (out is buf) == (lg % 2 == 0)
