@@ -164,11 +164,14 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)  # never returns
 
+    # the host driver of this pool only supports dmabuf IPC: RCCL's peer mappings fail with the legacy mode (exported on
+    # the GPU boxes already; set here as well, before the runtime loads, so that a bare launcher environment works)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import datetime
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world =int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
