@@ -68,8 +68,8 @@ __device__ __forceinline__ uint32_t xcd_map(uint32_t swizzle)
 // profiles/round5/ab_one_launch_block_map.jsonl; a pure streaming pass: + 1.6-2.4 %, probe_stream_shapes_32GiB.txt).  Bit 0
 // alone LOSES up to 11 % at some sizes, four or eight adjacent chunks per CU lose 1-9 %
 // (ab_one_launch_block_map_pairs_quads_octs_16GiB.jsonl); the XCDs' runs interleaved in pieces of 2 or 64 chunks instead of one
-// contiguous run each: level with it within the +- 1.5 % run-to-run spread (ab_one_launch_block_map_interleaved_runs.jsonl).  n = 512 (k_wave512) is the exception: - 1 ... - 2 % at 32 GiB,
-// so it keeps blockIdx.x.  Results do not depend on the map.
+// contiguous run each: level with it within the +- 1.5 % run-to-run spread (ab_one_launch_block_map_interleaved_runs.jsonl).
+// Results do not depend on the map.
 #ifndef FWA_ONE_LAUNCH_MAP
 #define FWA_ONE_LAUNCH_MAP 5
 #endif

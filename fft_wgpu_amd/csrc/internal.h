@@ -133,10 +133,6 @@ struct fwa_plan {
     // laboratory: the ring is this many times larger and the groups rotate through it (same launches, larger cache
     // footprint: prices what the Infinity Cache gives the ring)
     int64_t ring_rotate = 1;
-    // n = 512: 0 = k_small32<9>, 1 = k_wave512 (wave-private, a wave's four transforms one at a time).  With the plain
-    // block map 0.71 against 0.78 (profiles/round5/ab_wave512.jsonl); under the pair map of one_launch_block
-    // k_small32<9> reaches 0.785-0.825 against 0.766-0.789 over five boxes (ab_wave512_after_pair_map.jsonl): the default
-    int64_t wave = 0;
     // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
     int64_t small_reg = 1;
     std::vector<hipStream_t> istreams;

@@ -13,9 +13,6 @@ hipError_t launch_chunk(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32
 // 512 <= n <= 32768: 32 points per thread, one exchange (512, 1024) or two (kernels_small.hip: k_small32); in place allowed
 hipError_t launch_small32(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           hipStream_t st);
-// n = 512, plan key "wave" = 1 (the alternative to k_small32<9>): every wave walks 16 KiB = four transforms linearly and takes them one at a time, 8 x 8 x 8
-// with two exchanges through its own LDS plane, no workgroup barrier (wave_kernel.h: k_wave512); in place allowed
-hipError_t launch_wave512(int dir, const v2f *src, v2f *dst, const v2f *tw, uint64_t batch, float scale, hipStream_t st);
 // last pass of a two-pass plan n = n1 * 2^lg_l (lg_l = 9 .. 12, n <= 2^28): 16 adjacent rows per workgroup (8 from 2048-point rows), 32 points
 // per thread, transposed store out[k1 + n1*k2] (kernels_rows32.hip: k_rows32); tw = half table of W_{2^lg_l}
 bool rows32_supported(uint32_t lg_l);

@@ -401,8 +401,6 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
 #endif
             if (plan->n <= 256)
                 e = fwa::launch_chunk(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
-            else if (plan->n == 512 && plan->wave)
-                e = fwa::launch_wave512(dir, a, out, tb.tw_half, plan->batch, scale, st);
             else
                 e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
             break;

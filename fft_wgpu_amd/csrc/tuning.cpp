@@ -46,7 +46,6 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         }
     }
     else if (k == "small_reg") *value = plan->small_reg;
-    else if (k == "wave") *value = (plan->path == PATH_SMALL && plan->n == 512) ? plan->wave : 0;
     else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "rows32") *value = plan->rows32;
     else if (k == "colsw") *value = plan->colsw;
@@ -185,12 +184,6 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         int64_t &flag = k == "p1_gen" ? plan->p1_gen : k == "rows32" ? plan->rows32
                         : k == "colsw" ? plan->colsw : plan->tile_ring;
         flag = value != 0;
-        return FWA_OK;
-    }
-    if (k == "wave") {
-        if (plan->path != PATH_SMALL || plan->n != 512)
-            return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n = 512");
-        plan->wave = value != 0;
         return FWA_OK;
     }
     if (k == "small_reg") {

@@ -197,12 +197,9 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  *   "p1_gen" (tiled plans whose first factor is 1024: 1 = the 2^20 pipeline's column kernel at run-time
  *   pitch as pass A (default), 0 = the generic tile kernel),
  *   "rows32" (two-pass tiled plans whose second factor is 512 .. 4096: 1 = 32-point-per-thread row kernel with the
- *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 and 4096 exist only in the former),
- *   "wave" (n = 512: 0 = the 16-threads-per-transform kernel of the other one-launch sizes (default), 1 = the wave-private
- *   kernel, every wave takes its four transforms one at a time: faster before the one-launch kernels got their block map,
- *   level or slower since).
+ *   transposed store as last pass (default), 0 = the generic tile kernel; 2048 and 4096 exist only in the former).
  * Settable with fwa_plan_set_i64 before the first exec: "group", "streams", "xcd_swizzle", "factors", "colsw",
- * "tile_ring", "p1_gen", "rows32", "wave", "path" (2 anywhere).
+ * "tile_ring", "p1_gen", "rows32", "path" (2 anywhere).
  * fwa_ctx_get_i64: "device", "table_builds", "table_cache_hits", "ring_allocs", "ring_reuses", "pooled_ring_bytes",
  * "last_plan_create_us", "mem_free_bytes", "mem_total_bytes", "chain_streams" (chain streams created so far),
  * "chain_checks" / "chain_rejects" (candidates tested / discarded because they did not overlap the other chains),

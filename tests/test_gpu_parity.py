@@ -544,11 +544,10 @@ def test_onlyinverse_plus_normalize_equals_inverse(gpu, oracle):
 
 
 @pytest.mark.parametrize("batch", [1, 3, 4, 15, 16, 17, 61, 4099])
-def test_n512_wave_private_kernel_and_its_alternative(gpu, oracle, batch):
-    """n = 512, the reference's own length (examples/basic.rs:32,66): the default kernel k_small32<9> ("wave" = 0) and the
-    alternative k_wave512 ("wave" = 1: every wave walks 16 KiB = four transforms and takes them one at a time), all three
-    transforming plans, against the fp64 DFT; batches that leave a wave (4 transforms), a workgroup (16) and the last chunk
-    ragged; the result lands in the second buffer (odd log2 n, processor.rs:153-157); the two kernels agree to rounding."""
+def test_n512_the_references_own_length_at_ragged_batches(gpu, oracle, batch):
+    """n = 512, the reference's own length (examples/basic.rs:32,66), through k_small32<9> (16 threads per transform, 16
+    transforms per workgroup), all three transforming plans, against the fp64 DFT; batches that leave a wave (4 transforms),
+    a workgroup (16) and the last workgroup ragged; the result lands in the second buffer (odd log2 n, processor.rs:153-157)."""
     fw, dev, queue = gpu
     n = 512
     x = oracle.gen_input(n, batch, first_transform=batch)
@@ -556,20 +555,9 @@ def test_n512_wave_private_kernel_and_its_alternative(gpu, oracle, batch):
         r = oracle.dft_f64(x, n, direction)
         if kind == "Inverse":
             r = r / n
-        got = {}
-        for wave in (1, 0):
-            y, which, plan = _run(fw, dev, queue, kind, x, n, wave=wave)
-            assert which == 1 and plan.get("wave") == wave and plan.get("path") == 0 and plan.get("launches_per_exec") == 1
-            _check(oracle, y, r, n)
-            got[wave] = y
-        d = np.abs(got[1].astype(np.complex128) - got[0]).max() / np.abs(r).max()
-        assert d <= 2e-6, (kind, d)
-    # the key exists for n = 512 only
-    src = _upload(fw, dev, queue, oracle.gen_input(1024, 2))
-    p = fw.Forward(dev, queue, src, 1024)
-    with pytest.raises(fw.FwaError) as e:
-        p.set("wave", 1)
-    assert e.value.status == 6 and p.get("wave") == 0
+        y, which, plan = _run(fw, dev, queue, kind, x, n)
+        assert which == 1 and plan.get("path") == 0 and plan.get("launches_per_exec") == 1
+        _check(oracle, y, r, n)
 
 
 def test_calibration_copy_is_a_copy(gpu, oracle):
@@ -630,10 +618,10 @@ def test_config_c3_full_size_sampled(gpu, oracle):
         assert mx <= REL_TOL
 
 
-@pytest.mark.parametrize("lg,wave", [(9, 0), (9, 1), (6, None), (12, None)])
-def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg, wave):
+@pytest.mark.parametrize("lg", [9, 6, 12])
+def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg):
     """The one-launch kernels at C3's footprint (2^32 samples = 32 GiB: byte offsets beyond 2^32, half a million workgroups,
-    the pair block map over the whole grid): n = 512 (2^23 transforms; k_small32<9> and, with "wave" = 1, k_wave512; the result
+    the pair block map over the whole grid): n = 512 (2^23 transforms through k_small32<9>; the result
     lands in the plan's second buffer), k_chunk (64) and k_small32 with its look-ups ahead of the data (4096).  Sampled transforms -- the first, the last, some in between, one beyond every 4-GiB
     boundary -- against the fp64 DFT of the generator's output, then the scaled inverse restores the input at full size."""
     fw, dev, queue = gpu
@@ -644,8 +632,6 @@ def test_one_launch_kernels_at_the_full_footprint_sampled(gpu, oracle, lg, wave)
     enc = dev.create_command_encoder()
     dev.fill_synthetic(buf, n, encoder=enc)
     plan = fw.Forward(dev, queue, buf, n)
-    if wave is not None:
-        plan.set("wave", wave)
     out = plan.proc(enc)
     enc.synchronize()
     assert plan.get("path") == 0 and plan.get("launches_per_exec") == 1 and (out is buf) == (lg % 2 == 0)

@@ -1,7 +1,9 @@
-// wave_kernel.h -- k_wave512, the wave-private one-launch kernel for n = 512, as a template (kernels_wave.hip: the library's
-// instantiations and launcher; tools/wave_probe.hip: knock-out and alternative variants for timing).  Plan key "wave" = 1
-// selects it; the default at 512 is k_small32<9>, which has been level or ahead since the one-launch kernels got their block
-// map (device_common.h: one_launch_block; profiles/round5/ab_wave512_after_pair_map.jsonl: 0.785-0.825 against 0.766-0.789).
+// tools/wave_kernel.h -- k_wave512, the wave-private one-launch kernel for n = 512 (round 5; tools/wave_probe.hip times it
+// beside its variants).  NOT in the library any more: it was the product's n = 512 kernel (plan key "wave") while it led
+// k_small32<9> by 9 % (0.78 against 0.71, profiles/round5/ab_wave512.jsonl); the block map it led to (device_common.h:
+// one_launch_block) then lifted k_small32<9> to 0.785-0.825 against 0.766-0.789 for this kernel over five boxes
+// (ab_wave512_after_pair_map.jsonl), and a kernel that loses is recorded and removed.  The product-side wiring that was
+// measured and tested (launcher, plan key, parity tests) is profiles/round5/wave512_product_kernel.patch.
 //
 // One 256-thread workgroup per 64-KiB-aligned chunk, every WAVE walks its own 16 KiB = four whole transforms front to back
 // with 32 loads of 512 contiguous bytes (the streaming shape of DESIGN.md 2.1) and never addresses global memory any other

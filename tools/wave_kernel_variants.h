@@ -1,7 +1,7 @@
 // tools/wave_kernel_variants.h -- the alternatives of the n = 512 wave-private kernel that were measured and NOT shipped
 // (tools/wave_probe.hip; results: profiles/round5/probe_wave512_variants.jsonl): k_wave512 here = the four transforms of a
-// wave side by side (0.707 of the roofline), k_wave512s<PERSIST = false> = what the library ships as fwa::k_wave512
-// (fft_wgpu_amd/csrc/wave_kernel.h, 0.784), k_wave512s<PERSIST = true> = the persistent form (0.64-0.67).
+// wave side by side (0.707 of the roofline), k_wave512s<PERSIST = false> = what the library shipped for a while as fwa::k_wave512
+// (tools/wave_kernel.h, 0.784), k_wave512s<PERSIST = true> = the persistent form (0.64-0.67).
 //
 // One 256-thread workgroup per 64-KiB-aligned chunk, every WAVE walks its own 16 KiB = four whole transforms front to back
 // with 32 loads of 512 contiguous bytes (the streaming shape of DESIGN.md 2.1) -- and, unlike k_small32<9> (16 threads per

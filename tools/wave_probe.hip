@@ -1,7 +1,7 @@
 // The n = 512 wave-private kernel: where the time of the side-by-side form goes (parts knocked out -- no twiddles, no LDS
 // exchanges, no arithmetic at all: timing only, nothing meaningful is computed) and the forms that take a wave's four
-// transforms one at a time, persistent or not (tools/wave_kernel_variants.h), beside the library kernel
-// (fft_wgpu_amd/csrc/wave_kernel.h), in place and out of place, at a footprint of 2^lg samples.
+// transforms one at a time, persistent or not (tools/wave_kernel_variants.h), beside the kernel the library shipped for a
+// while (tools/wave_kernel.h), in place and out of place, at a footprint of 2^lg samples.
 //   wave_probe [log2_samples = 32] [rounds = 3]
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ifft_wgpu_amd/csrc -Itools tools/wave_probe.hip -o tools/wave_probe
 #include <algorithm>
