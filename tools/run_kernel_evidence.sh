@@ -1,8 +1,8 @@
 #!/bin/bash
 # tools/run_kernel_evidence.sh OUT -- rocprofv3 evidence for the one-launch kernels that changed in round 5: per-kernel
 # durations (--kernel-trace --stats) and L2<->fabric traffic (separate --pmc FETCH_SIZE / WRITE_SIZE passes) of three execs
-# over 2^32 samples at n = 64, 512, 1024, 2048, 4096 (the committed round-5 file also has n = 512 through k_wave512, the
-# library's kernel for that length at the time: its "default" entry; "wave=0" there is k_small32<9>).
+# over 2^32 samples at n = 64, 512, 1024, 2048, 4096 (profiles/round5/kernel_evidence_one_launch_with_wave512.txt is the
+# same job while the library had k_wave512: its "default" entry at 512; "wave=0" there is k_small32<9>).
 set -e
 O=${1:-gpurun_out/kernel_evidence.txt}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
