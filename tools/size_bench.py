@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fft_wgpu_amd as fw  # noqa: E402
 
 
+WARM_MS = 60.0
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
@@ -33,16 +36,27 @@ def main():
         plan = fw.Forward(dev, queue, view, n)
         for key, val in kv.items():
             plan.set(key, val)
-        reps = 5 if n * batch >= (1 << 24) else 50
+        reps = 5 if n * batch >= (1 << 31) else (15 if n * batch >= (1 << 24) else 50)
         times = []
-        for r in range(reps + 1):
+        # Warm-up: at least one exec and at least WARM_MS of them.  For some tens of milliseconds after a multi-GiB hipMalloc /
+        # hipFree (a plan of odd log2 n allocates its second buffer) kernels on this part run up to 15 % slower, whatever they
+        # touch (profiles/round5/probe_small_footprint_drift.jsonl: 0.82 -> 0.70 ms over the first 20 execs at 2 GiB, flat when
+        # the same plan is created a second time); at 32 GiB one exec outlasts it, at 2 GiB five timed execs sat inside it.
+        warmed, r = 0.0, 0
+        while r < reps + 1:
             dev.fill_synthetic(view, n, scale=2.0 ** -20, encoder=enc)
             a, b = fw.Event(dev), fw.Event(dev)
             a.record(enc)
             plan.proc(enc)
             b.record(enc)
-            if r:
-                times.append(a.elapsed_ms(b))
+            ms = a.elapsed_ms(b)
+            if warmed < WARM_MS:
+                warmed += ms
+                if r == 0:
+                    r = 1
+                continue
+            times.append(ms)
+            r += 1
         ms = sorted(times)[len(times) // 2]
         print(json.dumps({"lg_n": lg, "batch": batch, "footprint_GiB": round(n * batch * 8 / 2 ** 30, 3), "path": plan.get("path"), "factors": plan.get("factors"), "launches": plan.get("launches_per_exec"),
                           "ms": round(ms, 4), "ms_all": [round(t, 3) for t in times], "Gsamples_s": round(n * batch / ms / 1e6, 2),
