@@ -78,6 +78,16 @@ def main():
                 blockers[name] = (bl, dev.wrap_buffer(bl.device_ptr, blk), dev.wrap_buffer(bl.device_ptr + blk, blk))
         t = {name: [] for name in ctx}
         reps = 12 if lat else args.reps
+        if not lat:   # >= 60 ms of untimed execs per library: the transient after multi-GiB allocations (tools/size_bench.py)
+            for name, (dev, queue, enc) in ctx.items():
+                warmed = 0.0
+                while warmed < 60.0:
+                    dev.fill_synthetic(bufs[name], n, scale=2.0 ** -20, encoder=enc)
+                    a, b = fw.Event(dev), fw.Event(dev)
+                    a.record(enc)
+                    plans[name].proc(enc)
+                    b.record(enc)
+                    warmed += a.elapsed_ms(b)
         for rd in range(args.rounds + 1):
             for name, (dev, queue, enc) in ctx.items():
                 for r in range(reps):

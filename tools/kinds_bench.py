@@ -20,14 +20,18 @@ def main():
                  "Onlyinverse": fw.Onlyinverse(dev, queue, a, b, n), "Normalize": fw.Normalize(dev, queue, a, b, n)}
         for kind, plan in plans.items():
             times = []
-            for r in range(8):
+            warmed = 0.0      # >= 60 ms of untimed execs first: the transient after multi-GiB allocations (tools/size_bench.py)
+            while len(times) < 9:
                 dev.fill_synthetic(a, n, scale=2.0 ** -20, encoder=enc)
                 e0, e1 = fw.Event(dev), fw.Event(dev)
                 e0.record(enc)
                 plan.proc(enc)
                 e1.record(enc)
-                if r:
-                    times.append(e0.elapsed_ms(e1))
+                ms = e0.elapsed_ms(e1)
+                if warmed < 60.0:
+                    warmed += ms
+                else:
+                    times.append(ms)
             ms = sorted(times)[len(times) // 2]
             print(json.dumps({"lg_n": lg, "batch": batch, "kind": kind, "ms": round(ms, 4),
                               "Gsamples_s": round(n * batch / ms / 1e6, 1),
