@@ -17,7 +17,9 @@ devices than --gpus.
 Order of one run: rank 0 times the CPU baseline first (the oracle's restatement of the reference algorithm on
 the host cores, ~12 s, nothing on the GPU yet; the other ranks wait in the rendezvous, timeout 300 s), then the
 GPU phase -- warm-up, the K timed steps, the stream-ceiling calibration and a 100-exec spread leg on rank 0 (HIP
-events only, not part of `value`), and for N > 1 the slab-movement leg (below).  The line carries "gpu_phase_s".
+events only, not part of `value`), the batch-1 configurations of BASELINE.json (`"configs"`: N = 1024 = C1's shape, C2 = 2^20,
+C5 = 2^24, `--config-execs` execs each with HIP events, one exec of each checked against the fp64 DFT; rank 0, not part of
+`value`), and for N > 1 the slab-movement leg (below).  The line carries "gpu_phase_s".
 
 Timing: K steps inside barrier + torch.cuda.synchronize() brackets, wall clock, MAX over ranks.
 Because a forward FFT multiplies the RMS by 2^10 and `proc` works in place, the K steps run in
@@ -146,6 +148,84 @@ def self_launch(args):
     raise SystemExit(supervise(procs))
 
 
+CONFIG_SHAPES = (("C1_shape", 10, "BASELINE.json configs[0] (its shape on the HIP path; the lavapipe leg cannot run offline)"),
+                 ("C2", 20, "BASELINE.json configs[1]"),
+                 ("C5", 24, "BASELINE.json configs[4]"))
+
+
+def config_shapes(fw, dev, queue, enc, checker, reps):
+    """The single-GPU batch-1 configurations of BASELINE.json beside the headline (rank 0, after the timed region, never part of
+    `value`): N = 1024 (C1's shape), 2^20 (C2), 2^24 (C5), one transform each through `Forward.proc` (reference
+    src/processor.rs:110-158).  Per shape: what the plan chose, HIP events around ONE `proc` on an idle stream (`reps` times;
+    the input regenerated before every exec, outside the events), the same with a blocker queued first so that every launch of
+    the exec is already in the queue when the device reaches the first event, Gsamples/s and the fraction of the 8 TB/s roofline
+    from the idle-stream median, and a parity figure of ONE exec: max |y - r| / max |r| against the fp64 DFT of the same input
+    (C1, C2; `checker` = the oracle's fwo_dft_f64 when the CPU-baseline leg loaded it, numpy.fft in float64 otherwise) or, at
+    2^24, against the closed form of a unit impulse's transform exp(-2 pi i p k / n) evaluated in float64 (pins every output bin,
+    the sign and the order without a 2^24-point CPU transform in the bench run)."""
+    import numpy as np
+    out = {}
+    blk = 256 << 20
+    blocker = dev.create_buffer(2 * blk)
+    bsrc, bdst = dev.wrap_buffer(blocker.device_ptr, blk), dev.wrap_buffer(blocker.device_ptr + blk, blk)
+    for name, lg, what in CONFIG_SHAPES:
+        n = 1 << lg
+        buf = dev.create_buffer(n * fw.COMPLEX_BYTES)
+        plan = fw.Forward(dev, queue, buf, n)
+        t = {}
+        for mode in ("idle", "queued"):
+            ts = []
+            for r in range(reps + 5):
+                dev.fill_synthetic(buf, n, scale=2.0 ** -20, encoder=enc)
+                enc.synchronize()
+                a, b = fw.Event(dev), fw.Event(dev)
+                if mode == "queued":
+                    dev.calib_copy(bdst, bsrc, blk, encoder=enc)
+                a.record(enc)
+                plan.proc(enc)
+                b.record(enc)
+                ms = a.elapsed_ms(b)
+                if r >= 5:
+                    ts.append(ms * 1e3)
+            ts.sort()
+            t[mode] = ts
+        # parity of one exec
+        if lg <= 20:
+            dev.fill_synthetic(buf, n, encoder=enc)
+            x = buf.map_read(stream=enc)
+            y = plan.proc(enc).map_read(stream=enc)
+            if checker is not None:
+                ref, kind = checker.dft_f64(x, n, -1), "oracle.dft_f64 (fp64 DFT of the same input)"
+            else:
+                ref, kind = np.fft.fft(x.astype(np.complex128)), "numpy.fft float64 (--no-cpu-baseline: the oracle is not loaded)"
+        else:
+            p = 0x9E3779 % n | 1          # an odd position: every bin gets its own phase
+            x = np.zeros(n, dtype=np.complex64)
+            x[p] = 1.0
+            queue.write_buffer(buf, 0, x, encoder=enc)
+            y = plan.proc(enc).map_read(stream=enc)
+            k = np.arange(n, dtype=np.int64)
+            ang = (-2.0 * np.pi / n) * ((k * p) % n).astype(np.float64)
+            ref, kind = np.cos(ang) + 1j * np.sin(ang), f"closed form of a unit impulse at {p}, float64"
+        max_rel = float(np.abs(y.astype(np.complex128) - ref).max() / np.abs(ref).max())
+        med = t["idle"][len(t["idle"]) // 2]
+        out[name] = {"config": what, "fft_len": n, "batch": 1, "plan_path": plan.get("path"), "factors": plan.get("factors"),
+                     "launches": plan.get("launches_per_exec"), "execs": reps,
+                     "us_median": round(med, 3), "us_min": round(t["idle"][0], 3), "us_p90": round(t["idle"][(len(t["idle"]) * 9) // 10], 3),
+                     "us_queued_median": round(t["queued"][len(t["queued"]) // 2], 3), "us_queued_min": round(t["queued"][0], 3),
+                     "Gsamples_per_s": n / (med * 1e-6) / 1e9,
+                     "frac": ALGO_BYTES_PER_SAMPLE * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     "parity_max_rel": max_rel, "parity_ok": bool(max_rel <= 1e-5), "parity_checker": kind}
+        plan.destroy()
+        buf.destroy()
+    for b in (bsrc, bdst, blocker):
+        b.destroy()
+    out["_clock"] = ("HIP events around one Forward.proc on the launch stream; us_* = idle stream (the host's launch calls are inside the "
+                     "interval: what a caller sees), us_queued_* = behind a 256-MiB blocker copy (device-side time of the launches alone); "
+                     "frac = 16 B x N / us_median / 8 TB/s; batch-1 shapes live in the Infinity Cache and are launch-latency bound")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +239,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spread", type=int, default=100, help="extra execs timed one by one after the K steps (0 = off)")
     ap.add_argument("--no-movement", action="store_true", help="N > 1: skip the slab scatter / gather leg")
+    ap.add_argument("--config-execs", type=int, default=200,
+                    help="execs per batch-1 configuration (C1's shape, C2, C5) timed after the headline on rank 0 (0 = off)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -187,8 +269,10 @@ def main():
     # CPU baseline on rank 0 BEFORE the rendezvous and before anything runs on the GPU: afterwards the run is one
     # contiguous GPU phase.  The other ranks wait for rank 0's store inside init_process_group (RENDEZVOUS_TIMEOUT_S).
     cpu = None
+    checker = None     # the oracle, when this run loaded it: also checks one exec of each batch-1 configuration (config_shapes)
     if rank == 0 and not args.no_cpu_baseline:
         import oracle  # checker only: times the CPU restatement of the reference algorithm beside the GPU number
+        checker = oracle
         cores = usable_cores()
         cb = max(cores, 8)
         sps, reps = oracle.bench_forward(args.fft_len, cb, threads=cores, min_seconds=args.cpu_seconds)
@@ -303,7 +387,7 @@ def main():
     #  * out of place (8 GiB -> another 8 GiB, the same launch shape).
     # With N > 1 in rehearsal the ranks share one GPU: calibration figures would mean nothing and are skipped.
     copy_gbps = stream_gbps = None
-    spread = single_pass = None
+    spread = single_pass = shapes = None
     if rank == 0 and not rehearse:
         def rate(dst, src, nb, reps=3):
             dev.calib_copy(dst, src, nb, encoder=enc)
@@ -354,9 +438,13 @@ def main():
             sp.sort()
             spread = {"execs": len(sp), "ms_p10": sp[len(sp) // 10], "ms_p50": sp[len(sp) // 2], "ms_p90": sp[(len(sp) * 9) // 10],
                       "ms_min": sp[0], "ms_max": sp[-1]}
+        # the other single-GPU configurations of BASELINE.json (batch 1: latency shapes), after everything the headline needs
+        if args.config_execs > 0 and n == (1 << 20):
+            shapes = config_shapes(fw, dev, queue, enc, checker, args.config_execs)
     enc.synchronize()
+    per_rank_ev_min = all_gather_f64(min(step_ms_events))
 
-    def build_line(movement):
+    def build_line():
         samples_per_step = n * batch * world
         ms_per_step = wall_max / args.steps * 1e3
         value = samples_per_step / (wall_max / args.steps) / 1e9
@@ -408,7 +496,7 @@ def main():
                          "measured_floors": floors, "isolated_kernel_us": isolated,
                          "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group "
                                    "of transforms, alternating over the chains)",
-                         "ms_per_exec_hip_events": slow_ms, "ms_min": min(step_ms_events),
+                         "ms_per_exec_hip_events": slow_ms, "ms_min": per_rank_ev_min[slow],
                          # rocprofv3's mean duration over the k_p1_1m and k_p2_1m launches must equal avg_launch_us
                          # (launches of different chains overlap: sum of durations / chains = exec time)
                          "per_launch": {"launches": launches, "chains": chains, "avg_launch_us": avg_launch_us,
@@ -422,10 +510,16 @@ def main():
                          "copy_out_of_place_GBps_same_run": copy_gbps,
                          "single_pass_reference_same_run": single_pass,
                          "exec_spread_hip_events": spread},
+            # C1's shape, C2 and C5 (batch 1) under the same clock, same run; never part of `value`
+            "configs": shapes,
             "cpu_baseline": cpu,
-            "movement": movement,
+            "movement": None,
             "gpu_phase_s": time.perf_counter() - t_gpu_phase,
         }
+
+    # The line is complete BEFORE the movement leg starts: if that leg hangs, the watchdog thread only fills in `movement` and
+    # prints -- it makes no library or HIP call while the main thread is parked in a sync on a possibly wedged device.
+    line = build_line() if rank == 0 else None
 
     # ---- movement leg (N > 1; never part of `value`) -------------------------------------------------------------------
     movement = None
@@ -444,7 +538,8 @@ def main():
                     further collective is safe.  The timed figures are complete: rank 0 prints the line with the failure
                     in `movement`, every rank leaves with status 0 (the measurement stands; the failure is in the line)."""
                     if rank == 0:
-                        print(json.dumps(build_line({"error": what})), flush=True)
+                        line["movement"] = {"error": what}
+                        print(json.dumps(line), flush=True)
                     else:
                         time.sleep(3.0)   # rank 0 prints first; a launcher may tear the job down at the first exit
                     os._exit(0)
@@ -465,7 +560,9 @@ def main():
                 dog.cancel()
 
     if rank == 0:
-        print(json.dumps(build_line(movement)), flush=True)
+        line["movement"] = movement
+        line["gpu_phase_s"] = time.perf_counter() - t_gpu_phase
+        print(json.dumps(line), flush=True)
     if use_dist:
         # the line is out: a closing barrier / communicator teardown that hangs must not turn a finished measurement into a
         # run killed at its time limit

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfft_wgpu_amd.so")
 LAB_LIB_PATH = os.environ.get("FWA_LAB_LIBRARY") or os.path.join(_HERE, "libfft_wgpu_amd_lab.so")  # the override is for tools/ A/B builds
 
 FWA_OK = 0
+ABI_VERSION = 4   # FWA_ABI_VERSION of the include/fft_wgpu_amd.h this binding was written against
 FORWARD, INVERSE_SCALED, INVERSE_UNSCALED, NORMALIZE = 0, 1, 2, 3
 STATUS_NAMES = {
     0: "FWA_OK", 1: "FWA_ERR_INVALID_ARG", 2: "FWA_ERR_OUT_OF_MEMORY", 3: "FWA_ERR_HIP",
@@ -104,6 +105,17 @@ def lib(lab=False):
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C fft_wgpu_amd/csrc{' lab' if lab is True else ''}`.  fft_wgpu_amd has no CPU fallback.")
         L = ctypes.CDLL(path)
+        # a stale library beside newer Python (or the reverse) is refused HERE, not at the first changed signature
+        try:
+            L.fwa_abi_version.restype = _I32
+            L.fwa_abi_version.argtypes = []
+            got = int(L.fwa_abi_version())
+        except AttributeError:
+            got = None
+        if got != ABI_VERSION:
+            raise RuntimeError(
+                f"{path} reports ABI version {got}, this binding was written for version {ABI_VERSION} of "
+                f"include/fft_wgpu_amd.h: rebuild the library (`make -C fft_wgpu_amd/csrc all lab`) from the same tree")
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here = header/library mismatch
             f.restype = res

@@ -30,6 +30,10 @@ int32_t fwa_buf_alloc(fwa_ctx *ctx, uint64_t bytes, fwa_buf **out)
     fwa_buf *b = new (std::nothrow) fwa_buf;
     if (!b) { (void)hipFree(p); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     b->ctx = ctx; b->p = p; b->bytes = bytes; b->owned = true; b->device = ctx->device;
+    {
+        std::lock_guard<std::mutex> lk(ctx->live_mu);
+        ctx->live_bufs.insert(b);
+    }
     *out = b;
     return FWA_OK;
 }
@@ -42,6 +46,10 @@ int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **o
     fwa_buf *b = new (std::nothrow) fwa_buf;
     if (!b) return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->ctx = ctx; b->p = device_ptr; b->bytes = bytes; b->owned = false; b->device = ctx->device;
+    {
+        std::lock_guard<std::mutex> lk(ctx->live_mu);
+        ctx->live_bufs.insert(b);
+    }
     *out = b;
     return FWA_OK;
 }
@@ -49,6 +57,10 @@ int32_t fwa_buf_wrap(fwa_ctx *ctx, void *device_ptr, uint64_t bytes, fwa_buf **o
 int32_t fwa_buf_free(fwa_buf *buf)
 {
     if (!buf) return FWA_OK;
+    if (buf->ctx) {
+        std::lock_guard<std::mutex> lk(buf->ctx->live_mu);
+        buf->ctx->live_bufs.erase(buf);
+    }
     if (buf->owned && buf->p) { (void)hipSetDevice(buf->device); (void)hipFree(buf->p); }
     delete buf;
     return FWA_OK;
@@ -57,6 +69,7 @@ int32_t fwa_buf_free(fwa_buf *buf)
 int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint64_t bytes, fwa_stream *stream)
 {
     if (!dst || (!host && bytes)) return fail(dst ? dst->ctx : nullptr, FWA_ERR_INVALID_ARG, "dst/host is NULL");
+    LIVE_HANDLE(dst, "the buffer");
     if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "upload range exceeds buffer");
     if (!bytes) return FWA_OK;
@@ -69,6 +82,7 @@ int32_t fwa_buf_upload(fwa_buf *dst, uint64_t dst_offset, const void *host, uint
 int32_t fwa_buf_download(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes, fwa_stream *stream)
 {
     if (!src || (!host && bytes)) return fail(src ? src->ctx : nullptr, FWA_ERR_INVALID_ARG, "src/host is NULL");
+    LIVE_HANDLE(src, "the buffer");
     if (src_offset > src->bytes || bytes > src->bytes - src_offset)
         return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
     if (!bytes) return FWA_OK;
@@ -114,9 +128,12 @@ int32_t fwa_buf_copy(fwa_buf *dst, uint64_t dst_offset, const fwa_buf *src, uint
                      fwa_stream *stream)
 {
     if (!dst || !src) return fail(nullptr, FWA_ERR_INVALID_ARG, "dst/src is NULL");
+    LIVE_HANDLE(dst, "the destination buffer");
+    LIVE_HANDLE(src, "the source buffer");
     if (dst_offset > dst->bytes || bytes > dst->bytes - dst_offset || src_offset > src->bytes ||
         bytes > src->bytes - src_offset)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy range exceeds buffer");
+    if (stream && !stream->ctx) return fail(dst->ctx, FWA_ERR_INVALID_ARG, "the stream's context has been destroyed");
     if (stream && stream->ctx != dst->ctx && stream->ctx != src->ctx)
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "the stream belongs to neither buffer's context");
     if (!bytes) return FWA_OK;
@@ -164,6 +181,7 @@ int32_t fwa_host_free(fwa_ctx *ctx, void *ptr)
 int32_t fwa_buf_download_async(void *host, const fwa_buf *src, uint64_t src_offset, uint64_t bytes, fwa_stream *stream)
 {
     if (!src || (!host && bytes)) return fail(src ? src->ctx : nullptr, FWA_ERR_INVALID_ARG, "src/host is NULL");
+    LIVE_HANDLE(src, "the buffer");
     if (src_offset > src->bytes || bytes > src->bytes - src_offset)
         return fail(src->ctx, FWA_ERR_INVALID_ARG, "download range exceeds buffer");
     if (!bytes) return FWA_OK;
@@ -181,6 +199,7 @@ int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform
                            fwa_stream *stream)
 {
     if (!dst || !fft_len) return fail(dst ? dst->ctx : nullptr, FWA_ERR_INVALID_ARG, "dst NULL or fft_len 0");
+    LIVE_HANDLE(dst, "the buffer");
     USE_DEVICE(dst->ctx);
     hipError_t e = fwa::launch_fill(static_cast<v2f *>(dst->p), seed, first_transform * (uint64_t)fft_len,
                                     dst->bytes / 8, scale, raw(stream));
@@ -191,6 +210,8 @@ int32_t fwa_fill_synthetic(fwa_buf *dst, uint64_t seed, uint64_t first_transform
 int32_t fwa_calib_copy(fwa_buf *dst, const fwa_buf *src, uint64_t bytes, fwa_stream *stream)
 {
     if (!dst || !src) return fail(nullptr, FWA_ERR_INVALID_ARG, "dst/src is NULL");
+    LIVE_HANDLE(dst, "the destination buffer");
+    LIVE_HANDLE(src, "the source buffer");
     if (bytes > dst->bytes || bytes > src->bytes || (bytes & 15))
         return fail(dst->ctx, FWA_ERR_INVALID_ARG, "copy size exceeds a buffer or is not a multiple of 16");
     USE_DEVICE(dst->ctx);

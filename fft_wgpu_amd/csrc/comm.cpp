@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -81,6 +82,16 @@ int32_t fail_nccl(const fwa_ctx *ctx, Rccl *r, ncclResult_t e, const char *what)
                          std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
 }
 
+// "" when HSA_ENABLE_IPC_MODE_LEGACY=0 is in the environment, otherwise the sentence appended to an RCCL failure
+std::string ipc_mode_hint()
+{
+    const char *v = std::getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    if (v && std::strcmp(v, "0") == 0) return "";
+    return std::string("; HSA_ENABLE_IPC_MODE_LEGACY is ") + (v ? "\"" + std::string(v) + "\"" : "unset") +
+           ": on hosts whose driver supports only dmabuf IPC RCCL's peer mappings fail unless HSA_ENABLE_IPC_MODE_LEGACY=0 "
+           "is in the environment before the HIP runtime loads (include/fft_wgpu_amd.h, fwa_comm)";
+}
+
 static_assert(sizeof(ncclUniqueId) == FWA_COMM_ID_BYTES, "FWA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
 
 struct Piece {  // one side of a point-to-point transfer: bytes at ptr, to / from `peer` (-1: none)
@@ -112,8 +123,13 @@ int32_t exchange(fwa_comm *c, const Piece *sends, size_t ns, const Piece *recvs,
         if (recvs[i].peer >= 0 && recvs[i].bytes) e = r->Recv(recvs[i].ptr, recvs[i].bytes, ncclInt8, recvs[i].peer,
                                                               c->comm, hs);
     const ncclResult_t ge = r->GroupEnd();
-    if (e != ncclSuccess) return fail_nccl(c->ctx, r, e, "ncclSend/ncclRecv");
-    if (ge != ncclSuccess) return fail_nccl(c->ctx, r, ge, "ncclGroupEnd");
+    if (e != ncclSuccess || ge != ncclSuccess) {
+        const int32_t rc = e != ncclSuccess ? fail_nccl(c->ctx, r, e, "ncclSend/ncclRecv")
+                                            : fail_nccl(c->ctx, r, ge, "ncclGroupEnd");
+        const std::string hint = ipc_mode_hint();   // peers are mapped on the first exchange
+        if (!hint.empty()) (void)fwa_int::fail(c->ctx, rc, std::string(fwa_last_error_string(c->ctx)) + hint);
+        return rc;
+    }
     return FWA_OK;
 }
 
@@ -152,7 +168,12 @@ int32_t fwa_comm_create(fwa_ctx *ctx, const uint8_t id[FWA_COMM_ID_BYTES], int32
     const ncclResult_t e = r->CommInitRank(&c->comm, world, u, rank);
     if (e != ncclSuccess) {
         delete c;
-        return fail_nccl(ctx, r, e, "ncclCommInitRank");
+        const int32_t rc = fail_nccl(ctx, r, e, "ncclCommInitRank");
+        // the one misconfiguration this library has met in the field: hosts whose driver only supports dmabuf IPC
+        // (include/fft_wgpu_amd.h, fwa_comm block)
+        const std::string hint = ipc_mode_hint();
+        if (!hint.empty()) (void)fwa_int::fail(ctx, rc, std::string(fwa_last_error_string(ctx)) + hint);
+        return rc;
     }
     c->ctx = ctx; c->world = world; c->rank = rank;
     *out = c;
@@ -283,16 +304,29 @@ int32_t move_slabs(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *sla
 
 }  // namespace
 
+// move_slabs allocates small host vectors: nothing may throw across the C ABI
+static int32_t move_slabs_nothrow(fwa_comm *comm, bool gather, int32_t root, const fwa_buf *slab, const fwa_buf *full,
+                           uint32_t fft_len, uint64_t batch, fwa_stream *stream)
+{
+    try {
+        return move_slabs(comm, gather, root, slab, full, fft_len, batch, stream);
+    } catch (const std::bad_alloc &) {
+        return fwa_int::fail(comm ? comm->ctx : nullptr, FWA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    } catch (...) {
+        return fwa_int::fail(comm ? comm->ctx : nullptr, FWA_ERR_HIP, "unexpected exception in fwa_comm_scatter / gather");
+    }
+}
+
 int32_t fwa_comm_scatter(fwa_comm *comm, int32_t root, const fwa_buf *full_or_null, fwa_buf *slab, uint32_t fft_len,
                          uint64_t batch, fwa_stream *stream)
 {
-    return move_slabs(comm, false, root, slab, full_or_null, fft_len, batch, stream);
+    return move_slabs_nothrow(comm, false, root, slab, full_or_null, fft_len, batch, stream);
 }
 
 int32_t fwa_comm_gather(fwa_comm *comm, int32_t root, const fwa_buf *slab, fwa_buf *full_or_null, uint32_t fft_len,
                         uint64_t batch, fwa_stream *stream)
 {
-    return move_slabs(comm, true, root, slab, full_or_null, fft_len, batch, stream);
+    return move_slabs_nothrow(comm, true, root, slab, full_or_null, fft_len, batch, stream);
 }
 
 }  // extern "C"

@@ -264,6 +264,10 @@ int32_t fwa_ctx_destroy(fwa_ctx *ctx)
     for (auto s : ctx->chains) (void)hipStreamDestroy(s);
     // stream handles that outlive their context (a garbage-collected host language frees in any order) stay destroyable
     for (fwa_stream *st : ctx->live_streams) st->ctx = nullptr;
+    // ... and so do buffer and event handles: freed memory is never dereferenced through them, using one afterwards is
+    // FWA_ERR_INVALID_ARG (the device memory of an owned buffer is released by its own fwa_buf_free)
+    for (fwa_buf *b : ctx->live_bufs) b->ctx = nullptr;
+    for (fwa_event *ev : ctx->live_events) ev->ctx = nullptr;
     ctx->tables.clear();
     delete ctx;
     return FWA_OK;
@@ -295,6 +299,10 @@ int32_t fwa_ctx_get_i64(const fwa_ctx *ctx, const char *key, int64_t *value)
     else if (k == "chain_single_us") *value = ctx->chain_single_us;
     else if (k == "chain_check") *value = ctx->chain_check;
     else if (k == "live_streams") *value = (int64_t)ctx->live_streams.size();
+    else if (k == "live_buffers") {
+        std::lock_guard<std::mutex> lk(const_cast<fwa_ctx *>(ctx)->live_mu);
+        *value = (int64_t)ctx->live_bufs.size();
+    }
     else if (k == "mem_free_bytes" || k == "mem_total_bytes") {
         int cur = -1;
         size_t fr = 0, tot = 0;
@@ -420,12 +428,17 @@ int32_t fwa_event_create(fwa_ctx *ctx, fwa_event **out)
     fwa_event *ev = new (std::nothrow) fwa_event;
     if (!ev) { (void)hipEventDestroy(e); return fail(ctx, FWA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     ev->ctx = ctx; ev->e = e;
+    {
+        std::lock_guard<std::mutex> lk(ctx->live_mu);
+        ctx->live_events.insert(ev);
+    }
     *out = ev;
     return FWA_OK;
 }
 int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream)
 {
     if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    LIVE_HANDLE(ev, "the event");
     USE_DEVICE(ev->ctx);
     HIP_TRY(ev->ctx, hipEventRecord(ev->e, raw(stream)));
     return FWA_OK;
@@ -433,6 +446,7 @@ int32_t fwa_event_record(fwa_event *ev, fwa_stream *stream)
 int32_t fwa_event_synchronize(fwa_event *ev)
 {
     if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    LIVE_HANDLE(ev, "the event");
     USE_DEVICE(ev->ctx);
     HIP_TRY(ev->ctx, hipEventSynchronize(ev->e));
     return FWA_OK;
@@ -440,6 +454,7 @@ int32_t fwa_event_synchronize(fwa_event *ev)
 int32_t fwa_stream_wait_event(fwa_stream *stream, fwa_event *ev)
 {
     if (!ev) return fail(nullptr, FWA_ERR_INVALID_ARG, "event is NULL");
+    LIVE_HANDLE(ev, "the event");
     USE_DEVICE(ev->ctx);
     HIP_TRY(ev->ctx, hipStreamWaitEvent(raw(stream), ev->e, 0));
     return FWA_OK;
@@ -447,6 +462,8 @@ int32_t fwa_stream_wait_event(fwa_stream *stream, fwa_event *ev)
 int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms)
 {
     if (!start || !end || !ms) return fail(nullptr, FWA_ERR_INVALID_ARG, "NULL argument");
+    LIVE_HANDLE(start, "the event");
+    LIVE_HANDLE(end, "the event");
     USE_DEVICE(end->ctx);
     HIP_TRY(end->ctx, hipEventSynchronize(end->e));
     HIP_TRY(end->ctx, hipEventElapsedTime(ms, start->e, end->e));
@@ -455,6 +472,10 @@ int32_t fwa_event_elapsed_ms(fwa_event *start, fwa_event *end, float *ms)
 int32_t fwa_event_destroy(fwa_event *ev)
 {
     if (!ev) return FWA_OK;
+    if (ev->ctx) {
+        std::lock_guard<std::mutex> lk(ev->ctx->live_mu);
+        ev->ctx->live_events.erase(ev);
+    }
     (void)hipEventDestroy(ev->e);
     delete ev;
     return FWA_OK;

@@ -13,8 +13,10 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/fft_wgpu_amd.h"
@@ -83,6 +85,13 @@ struct fwa_ctx {
     // fwa_ctx_set_i64("chain_check", 0): new streams are taken as the runtime hands them out
     int64_t chain_check = 1;
     std::vector<int> peers_enabled;         // device ordinals this context's device has peer access to (enabled once)
+    // Every alive fwa_buf / fwa_event handle of this context (allocated or wrapped).  fwa_ctx_destroy clears their `ctx`,
+    // as it does for streams, so that a handle which outlives its context (garbage-collected hosts free in any order)
+    // answers FWA_ERR_INVALID_ARG instead of dereferencing freed memory.  `live_mu` guards the two sets and the stream list
+    // below only: buffers may be allocated and freed from several threads of one context.
+    std::mutex live_mu;
+    std::unordered_set<fwa_buf *> live_bufs;
+    std::unordered_set<fwa_event *> live_events;
 };
 struct fwa_stream {
     fwa_ctx *ctx = nullptr;   // nullptr once the context has been destroyed (the handle can still be destroyed)
@@ -91,14 +100,14 @@ struct fwa_stream {
     int device = -1;
 };
 struct fwa_buf {
-    fwa_ctx *ctx = nullptr;
+    fwa_ctx *ctx = nullptr;   // nullptr once the context has been destroyed: every entry point then refuses the handle
     void *p = nullptr;
     uint64_t bytes = 0;
     bool owned = false;
     int device = -1;          // for fwa_buf_free after the context is gone
 };
 struct fwa_event {
-    fwa_ctx *ctx = nullptr;
+    fwa_ctx *ctx = nullptr;   // nullptr once the context has been destroyed
     hipEvent_t e = nullptr;
 };
 
@@ -182,6 +191,14 @@ inline uint32_t ilog2(uint32_t n)
     return l;
 }
 inline hipStream_t raw(fwa_stream *s) { return s ? s->s : nullptr; }
+
+// A buffer / event handle whose context has been destroyed may still be freed, never used (include/fft_wgpu_amd.h,
+// "Lifetimes"): every entry point that takes one starts with this check.
+#define LIVE_HANDLE(h, what)                                                                              \
+    do {                                                                                                  \
+        if (!(h)->ctx)                                                                                    \
+            return fwa_int::fail(nullptr, FWA_ERR_INVALID_ARG, what " belongs to a context that has been destroyed"); \
+    } while (0)
 
 // ---- ctx_streams.cpp ----
 int32_t overlapping_stream(fwa_ctx *ctx, const std::vector<hipStream_t> &peers, hipStream_t *out);

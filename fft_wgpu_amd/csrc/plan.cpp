@@ -279,6 +279,11 @@ int32_t fwa_plan_create(fwa_ctx *ctx, int32_t kind, uint32_t fft_len, fwa_buf *s
     if (!out) return fail(ctx, FWA_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!ctx || !src) return fail(ctx, FWA_ERR_INVALID_ARG, "ctx/src is NULL");
+    for (const fwa_buf *b : {(const fwa_buf *)src, (const fwa_buf *)src2_or_null}) {
+        if (b && !b->ctx) return fail(ctx, FWA_ERR_INVALID_ARG, "a buffer belongs to a context that has been destroyed");
+        if (b && b->ctx->device != ctx->device)
+            return fail(ctx, FWA_ERR_INVALID_ARG, "a buffer lives on another device than the plan's context");
+    }
     if (kind < FWA_FORWARD || kind > FWA_NORMALIZE) return fail(ctx, FWA_ERR_INVALID_ARG, "unknown plan kind");
     if (!is_pow2(fft_len)) return fail(ctx, FWA_ERR_INVALID_ARG, "fft_len must be a power of two >= 1");
     if (fft_len > (1u << 30)) return fail(ctx, FWA_ERR_UNSUPPORTED, "fft_len above 2^30 is not supported");

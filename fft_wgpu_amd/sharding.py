@@ -210,7 +210,11 @@ class ShardedBatch:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(max_workers=len(self.plans), thread_name_prefix="fwa-shard")
+            from concurrent.futures import wait
             futures = [self._pool.submit(p.proc, e) for p, e in zip(self.plans, self.encoders)]
+            # EVERY shard has finished enqueueing before the first failure is re-raised: a destroy() issued from the caller's
+            # except block must not race with shards that are still inside fwa_plan_exec
+            wait(futures)
             self.results = [f.result() for f in futures]      # re-raises a shard's FwaError here
         else:
             self.results = [p.proc(e) for p, e in zip(self.plans, self.encoders)]
@@ -267,8 +271,9 @@ class ShardedBatch:
             self._pool.shutdown(wait=True)
             self._pool = None
         # contexts this object created go last (each holds its pooled ring slab, twiddle tables and chain streams until then);
-        # buffer and stream handles a caller still holds on them stay destroyable (include/fft_wgpu_amd.h, "Lifetimes").
-        # Devices the caller passed in are the caller's.
+        # buffer, stream and event handles a caller still holds on them stay destroyable, and USING one afterwards is
+        # FWA_ERR_INVALID_ARG, never a dangling pointer: fwa_ctx_destroy detaches the context's live handles
+        # (include/fft_wgpu_amd.h, "Lifetimes").  Devices the caller passed in are the caller's.
         if self._owns_devices:
             for d in self.devices:
                 d.destroy()

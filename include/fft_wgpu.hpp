@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -31,6 +32,16 @@ public:
     int32_t status;
 };
 
+// The shared library found at run time must implement the header this file was compiled against: a stale .so is refused
+// when the first Device is made (or the devices are enumerated), not at the first call whose signature has changed.
+inline void check_abi()
+{
+    const int32_t got = fwa_abi_version();
+    if (got != FWA_ABI_VERSION)
+        throw Error(FWA_ERR_UNSUPPORTED, "libfft_wgpu_amd.so reports ABI version " + std::to_string(got) +
+                                             ", include/fft_wgpu_amd.h is version " + std::to_string(FWA_ABI_VERSION));
+}
+
 // wgpu::AdapterInfo of one device ordinal (instance.enumerate_adapters(..), lib.rs:33-35)
 struct AdapterInfo {
     int ordinal = 0;
@@ -43,6 +54,7 @@ struct AdapterInfo {
 // One entry per visible device ordinal, no context created.  Empty when no device is visible (prepare_gpu -> None).
 inline std::vector<AdapterInfo> enumerate_devices()
 {
+    check_abi();
     std::vector<AdapterInfo> out;
     int32_t n = 0;
     if (fwa_device_count(&n) != FWA_OK) return out;
@@ -74,6 +86,7 @@ class Device {  // wgpu::Device (+ Instance/Adapter/Queue), lib.rs:29-62
 public:
     explicit Device(int ordinal = 0) : ordinal_(ordinal)
     {
+        check_abi();
         int32_t st = fwa_ctx_create(ordinal, &h_);
         if (st) throw Error(st, std::string("fwa_ctx_create: ") + fwa_last_error_string(nullptr));
     }
@@ -369,8 +382,16 @@ public:
             try { result_[i] = &plan_[i]->proc(*enc_[i]); } catch (...) { err[i] = std::current_exception(); }
         };
         std::vector<std::thread> workers;
-        for (size_t i = 1; i < n; ++i) workers.emplace_back(one, i);
+        workers.reserve(n - 1);
+        size_t started = 1;   // shards [1, started) have a worker; the rest are enqueued from this thread
+        try {
+            for (; started < n; ++started) workers.emplace_back(one, started);
+        } catch (const std::system_error &) {
+            // no more threads to be had: a vector of joinable threads must never be destroyed (std::terminate), so
+            // the shards without a worker fall back to serial enqueue below and the started ones are joined as usual
+        }
         one(0);
+        for (size_t i = started; i < n; ++i) one(i);
         for (std::thread &t : workers) t.join();
         for (const std::exception_ptr &e : err)
             if (e) std::rethrow_exception(e);

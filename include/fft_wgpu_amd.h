@@ -31,8 +31,10 @@
  * of the context captures a graph; fwa_ctx_set_i64(ctx, "chain_check", 0)
  * turns the check off.
  *
- * Lifetimes: plans and communicators go before their context, buffers before the plans that use them.  Buffer and
- * stream HANDLES may be destroyed after their context (hosts with garbage collection free in any order); using one is an error.
+ * Lifetimes: plans and communicators go before their context, buffers before the plans that use them.  Buffer, stream
+ * and event HANDLES may be destroyed after their context (hosts with garbage collection free in any order): the context
+ * keeps a list of its live handles and detaches them in fwa_ctx_destroy, so USING one afterwards -- upload, download,
+ * copy, plan creation, event record ... -- returns FWA_ERR_INVALID_ARG; it never touches freed memory.
  *
  * Errors: every function returns an fwa_status (0 = ok).  Nothing aborts or
  * throws across the ABI.  fwa_last_error_string() gives detail.
@@ -204,7 +206,7 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  * "last_plan_create_us", "mem_free_bytes", "mem_total_bytes", "chain_streams" (chain streams created so far),
  * "chain_checks" / "chain_rejects" (candidates tested / discarded because they did not overlap the other chains),
  * "chain_single_us" / "chain_pair_us" (the check's spin kernel alone / on all chains at once), "chain_check",
- * "live_streams" (alive fwa_stream handles of the context).
+ * "live_streams" / "live_buffers" (alive fwa_stream / fwa_buf handles of the context).
  *
  * Laboratory build only (fft_wgpu_amd/libfft_wgpu_amd_lab.so, `make -C fft_wgpu_amd/csrc lab`; the product library
  * answers FWA_ERR_UNSUPPORTED): kernel families that measured slower than the shipped ones, kept for A/B timing and
@@ -233,7 +235,12 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
  *    librccl is dlopen'ed on the first fwa_comm_* call; FWA_ERR_UNSUPPORTED if it cannot be loaded.
  * fwa_comm_unique_id: rank 0 makes the id and hands the 128 bytes to the other ranks by any means (file, socket,
  * torch.distributed store).  fwa_comm_create is collective over the `world` processes holding the same id, one rank per
- * device.  Scatter / gather are collective too, stream-ordered on `stream` (a stream of the communicator's context):
+ * device.  ENVIRONMENT: RCCL maps its peers' buffers through HIP IPC.  On hosts whose kernel driver supports only dmabuf
+ * IPC (every box of the pool this library was developed on) the process must have HSA_ENABLE_IPC_MODE_LEGACY=0 in its
+ * environment BEFORE the HIP runtime is loaded (i.e. before the first call into this library or into any other HIP user
+ * of the process; setenv() from main() is early enough, after fwa_ctx_create it is not): without it communicator creation
+ * or the first exchange fails inside RCCL ("hipIpcGetMemHandle: invalid argument" / ncclUnhandledCudaError).  When
+ * fwa_comm_create fails and the variable is unset or not "0", the error text says so.  Scatter / gather are collective too, stream-ordered on `stream` (a stream of the communicator's context):
  *   scatter: root's `full` (batch transforms) -> every rank's `slab` (>= its count transforms); `full` is ignored elsewhere
  *   gather : every rank's `slab` -> root's `full`
  * fwa_comm_sendrecv: the primitive under both -- one send and/or one receive in one group (rank < 0 = none); sending to the

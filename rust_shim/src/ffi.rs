@@ -1,4 +1,4 @@
-// ffi.rs -- the `extern "C"` block over include/fft_wgpu_amd.h (ABI version 3).  UNVERIFIED: never compiled here (no
+// ffi.rs -- the `extern "C"` block over include/fft_wgpu_amd.h (ABI version 4).  UNVERIFIED: never compiled here (no
 // rustc in the image).  Generated from the header's prototypes; tests/test_abi.py checks that this list and the header
 // declare the same symbols.
 #![allow(non_camel_case_types, dead_code)]
@@ -12,6 +12,9 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct fwa_comm { _private: [u8; 0] }
 
 pub const FWA_COMM_ID_BYTES: usize = 128;
+/// `FWA_ABI_VERSION` of the header this block was generated from; `wgpu_helper::Device::open` refuses a library that
+/// reports another one.
+pub const FWA_ABI_VERSION: i32 = 4;
 
 pub const FWA_OK: i32 = 0;
 pub const FWA_ERR_NO_DEVICE: i32 = 5;

@@ -248,6 +248,14 @@ pub struct CommandEncoderDescriptor<'a> {
 impl Device {
     /// `None` when no gfx950 device is usable (reference `prepare_gpu` -> `None`, `src/lib.rs:43,59`).
     pub fn open(ordinal: i32) -> Option<Device> {
+        // A libfft_wgpu_amd.so built from another version of the header is as unusable as no GPU at all: `None`, the
+        // answer the reference's `prepare_gpu` gives when nothing usable is found (`src/lib.rs:43,59`), rather than a
+        // call through a changed signature later on.
+        let abi = unsafe { fwa_abi_version() };
+        if abi != FWA_ABI_VERSION {
+            eprintln!("fft_wgpu: libfft_wgpu_amd.so reports ABI version {abi}, this crate binds version {FWA_ABI_VERSION}");
+            return None;
+        }
         let mut ctx: *mut fwa_ctx = ptr::null_mut();
         let st = unsafe { fwa_ctx_create(ordinal, &mut ctx) };
         if st == FWA_ERR_NO_DEVICE {

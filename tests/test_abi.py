@@ -209,3 +209,75 @@ def test_header_is_plain_c(tmp_path):
                    'int probe(void) { fwa_ctx *c = 0; int32_t n = 0; (void)c; return fwa_device_count(&n) + fwa_abi_version(); }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "c_user.o")])
+
+
+def _stub_library(tmp_path, version, name="libfft_wgpu_amd.so"):
+    """A shared library that only answers fwa_abi_version (what a stale build beside newer host code looks like)."""
+    import subprocess
+    src = tmp_path / "stub.c"
+    src.write_text("#include <stdint.h>\nint32_t fwa_abi_version(void) { return %d; }\n" % version)
+    out = tmp_path / name
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(out)])
+    return out
+
+
+def test_python_mirror_refuses_a_library_of_another_abi_version(tmp_path):
+    """`_ffi.lib()` compares fwa_abi_version() with the version the binding was written for when it
+    LOADS the library -- a stale .so reporting version 3 is refused before any signature is bound or any entry point called."""
+    import re
+    from fft_wgpu_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "fft_wgpu_amd.h")).read()
+    assert _ffi.ABI_VERSION == int(re.search(r"#define FWA_ABI_VERSION (\d+)", header).group(1))
+    stub = _stub_library(tmp_path, _ffi.ABI_VERSION - 1)
+    with pytest.raises(RuntimeError) as e:
+        _ffi.lib(str(stub))
+    assert f"ABI version {_ffi.ABI_VERSION - 1}" in str(e.value) and "rebuild" in str(e.value)
+    assert str(stub) not in _ffi._libs                      # a refused library is not cached as loaded
+    nothing = tmp_path / "libempty.so"                       # a library without the symbol at all is refused the same way
+    import subprocess
+    (tmp_path / "empty.c").write_text("int unrelated;\n")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(tmp_path / "empty.c"), "-o", str(nothing)])
+    with pytest.raises(RuntimeError) as e:
+        _ffi.lib(str(nothing))
+    assert "ABI version None" in str(e.value)
+
+
+def test_cpp_mirror_refuses_a_library_of_another_abi_version(tmp_path):
+    """fft_wgpu::Device's constructor (and enumerate_devices) throw Error(FWA_ERR_UNSUPPORTED) when the library found at run
+    time reports another FWA_ABI_VERSION than the header the host was compiled against -- before fwa_ctx_create is reached
+    (the stub does not even have it: lazy binding, the call would abort the process)."""
+    import subprocess
+    stub = _stub_library(tmp_path, 3)
+    src = tmp_path / "host.cpp"
+    src.write_text('#include <cstdio>\n#include "fft_wgpu.hpp"\n'
+                   'int main() {\n'
+                   '  int caught = 0;\n'
+                   '  try { fft_wgpu::Device d(0); } catch (const fft_wgpu::Error &e) { caught += e.status == FWA_ERR_UNSUPPORTED; std::puts(e.what()); }\n'
+                   '  try { (void)fft_wgpu::enumerate_devices(); } catch (const fft_wgpu::Error &e) { caught += e.status == FWA_ERR_UNSUPPORTED; }\n'
+                   '  return caught == 2 ? 0 : 1;\n}\n')
+    exe = tmp_path / "host"
+    # linked against the real library (every symbol resolves at link time), run against the stub (lazy binding: only the
+    # functions actually called are looked up)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-L" + os.path.join(ROOT, "fft_wgpu_amd"), "-lfft_wgpu_amd", "-pthread", "-Wl,-z,lazy", "-o", str(exe)])
+    r = subprocess.run([str(exe)], env=dict(os.environ, LD_LIBRARY_PATH=str(stub.parent)), capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "ABI version 3" in r.stdout and "version 4" in r.stdout
+
+
+def test_rust_shim_checks_the_abi_version_and_the_header_documents_the_ipc_mode():
+    """Item 3 (a) and (c): the Rust mirror refuses a library of another version where the reference's prepare_gpu answers
+    None (src/lib.rs:29-62); hosts of fwa_comm_* are told about HSA_ENABLE_IPC_MODE_LEGACY=0 in the header, in
+    INTEGRATION.md and -- when RCCL fails without it -- in the error text."""
+    ffi = open(os.path.join(ROOT, "rust_shim", "src", "ffi.rs")).read()
+    helper = open(os.path.join(ROOT, "rust_shim", "src", "wgpu_helper.rs")).read()
+    assert "ABI version 4" in ffi.split("\n")[0] and "pub const FWA_ABI_VERSION: i32 = 4;" in ffi
+    body = helper[helper.index("pub fn open(ordinal: i32) -> Option<Device>"):]
+    assert body.index("fwa_abi_version()") < body.index("fwa_ctx_create") and "return None" in body[:body.index("fwa_ctx_create")]
+    header = open(os.path.join(ROOT, "include", "fft_wgpu_amd.h")).read()
+    comm_block = header[header.index("multi-GPU: batch sharding"):header.index("typedef struct fwa_comm")]
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=0" in comm_block and "BEFORE the HIP runtime" in comm_block
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=0" in integration
+    comm = open(os.path.join(ROOT, "fft_wgpu_amd", "csrc", "comm.cpp")).read()
+    assert 'getenv("HSA_ENABLE_IPC_MODE_LEGACY")' in comm and "ipc_mode_hint()" in comm[comm.index("ncclCommInitRank"):]

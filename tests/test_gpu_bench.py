@@ -147,3 +147,27 @@ def test_a_failing_movement_leg_keeps_the_measured_line():
     line = _one_line(r.stdout)
     assert "on request" in line["movement"]["error"] and np.isfinite(line["value"]) and line["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["steps"] == 2
+
+
+def test_default_line_carries_every_single_gpu_config_of_baseline_json():
+    """C1's shape (1024 x 1), C2 (2^20 x 1) and C5 (2^24 x 1) are timed and checked INSIDE the
+    driver-run command, in a `configs` object of the one JSON line (BASELINE.json configs[0, 1, 4]; reference
+    src/processor.rs:110-158).  A fresh child with the headline batch cut down (the configs leg does not depend on it)."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--batch", "256", "--cpu-seconds", "1",
+                        "--spread", "0", "--config-execs", "200"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    line = _one_line(r.stdout)
+    cfg = line["configs"]
+    assert set(cfg) == {"C1_shape", "C2", "C5", "_clock"}
+    want = {"C1_shape": (1 << 10, 1, 1.0, 20.0), "C2": (1 << 20, 3, 8.0, 40.0), "C5": (1 << 24, 3, 60.0, 300.0)}
+    for name, (n, launches, lo_us, hi_us) in want.items():
+        c = cfg[name]
+        assert c["fft_len"] == n and c["batch"] == 1 and c["execs"] == 200 and c["launches"] == launches, c
+        assert lo_us < c["us_min"] <= c["us_median"] <= c["us_p90"] < hi_us, c
+        assert lo_us < c["us_queued_min"] <= c["us_queued_median"] < hi_us, c
+        assert abs(c["Gsamples_per_s"] - n / c["us_median"] / 1e3) <= 1e-6 * c["Gsamples_per_s"]
+        assert abs(c["frac"] - 16 * n / (c["us_median"] * 1e-6) / 8e12) <= 1e-9 and 0 < c["frac"] < 1
+        assert c["parity_ok"] is True and 0 < c["parity_max_rel"] <= 1e-5, c
+    assert "oracle.dft_f64" in cfg["C2"]["parity_checker"] and "impulse" in cfg["C5"]["parity_checker"]
+    # the headline is untouched by the extra leg: still the first-class fields of the contract
+    assert line["metric"].startswith("Gsamples/s") and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["cores"] >= 1

@@ -560,6 +560,61 @@ def test_n512_the_references_own_length_at_ragged_batches(gpu, oracle, batch):
         _check(oracle, y, r, n)
 
 
+# ---- the workgroup -> chunk map of the one-launch kernels on RAGGED grids ----
+# one_launch_block() (csrc/device_common.h) maps the largest prefix of the grid that is whole runs of 64 workgroups per XCD
+# (a multiple of 512 blocks) and leaves the remainder on the plain map.  Every other parity case has fewer than 512 blocks
+# (map inactive) or an exact multiple of 512 (no remainder): these grids have 513 .. 1023 blocks, i.e. a mapped prefix, a
+# plain-map tail AND a partial last chunk at once.  Every transform is checked: a chunk visited twice or not at all shows.
+@pytest.mark.parametrize("n,batch,blocks", [
+    (2, 700 * 4096 + 5, 701),       # k_chunk, 8192 samples per workgroup
+    (64, 700 * 128 + 3, 701),       # k_chunk, radix 16 x 4
+    (256, 33 * 513 + 7, 530),       # k_chunk at its largest length (32 transforms per workgroup)
+    (512, 16 * 700 + 5, 701),       # k_small32<9>: 16 transforms per workgroup
+    (1024, 8 * 600 + 3, 601),       # k_small32<10>: 8
+    (4096, 2 * 650 + 1, 651),       # k_small32<12>: 2
+    (8192, 700, 700),               # k_small32<13>: one transform per workgroup (ragged grid, whole chunks)
+    (16384, 600, 600),              # k_small32<14>: 512 threads
+    (32768, 520, 520),              # k_small32<15>: 1024 threads
+])
+def test_one_launch_block_map_on_ragged_grids(gpu, oracle, n, batch, blocks):
+    fw, dev, queue = gpu
+    per_wg = 8192 // n if n <= 256 else max(1, 256 // (n // 32))      # transforms per workgroup (launch_chunk / small32_xpw)
+    assert 512 < -(-batch // per_wg) == blocks < 1024
+    x = oracle.gen_input(n, batch, first_transform=17)
+    y, which, plan = _run(fw, dev, queue, "Forward", x, n)
+    assert plan.get("path") == 0 and plan.get("launches_per_exec") == 1 and which == (n.bit_length() - 1) % 2
+    # the SURVEY 8(c) metric per transform, vectorised (up to 2.9 M transforms here)
+    r = oracle.dft_f64(x, n, -1).reshape(batch, n)
+    d = np.abs(y.reshape(batch, n).astype(np.complex128) - r)
+    assert (d.max(axis=1) <= REL_TOL * np.abs(r).max(axis=1)).all()
+    assert (np.sqrt((d ** 2).sum(axis=1)) <= REL_TOL * np.sqrt((np.abs(r) ** 2).sum(axis=1))).all()
+
+
+def test_normalize_and_calibration_copy_on_ragged_grids(gpu, oracle):
+    """k_scale (Normalize, normalize.wgsl:9-12; and the in-place form of fwa_calib_copy) and k_copy on 701-block grids with a
+    partial last chunk: bit-exact against the oracle's normalize / the input."""
+    fw, dev, queue = gpu
+    n, batch = 64, 700 * 128 + 3                     # 701 workgroups of 8192 samples, the last one holds 3 transforms
+    x = oracle.gen_input(n, batch, first_transform=5)
+    a = _upload(fw, dev, queue, x)
+    b = dev.create_buffer(x.nbytes)
+    enc = dev.create_command_encoder()
+    out = fw.Normalize(dev, queue, a, b, n).proc(enc)        # log2 n even: reads buffer1, writes and returns buffer2
+    assert out is b
+    got = out.map_read(stream=enc)
+    assert np.array_equal(got.view(np.uint32), oracle.normalize_ref(x, n).view(np.uint32))
+    # out-of-place calibration copy: 701 whole 64-KiB chunks (k_copy, mapped prefix + plain tail) + a 16-byte-vector tail
+    nbytes = 701 * 65536 + 4096 + 16
+    src = dev.wrap_buffer(a.device_ptr, nbytes)
+    dst = dev.create_buffer(nbytes)
+    dev.calib_copy(dst, src, nbytes, encoder=enc)
+    assert np.array_equal(dst.map_read(stream=enc).view(np.uint32), x[:nbytes // 8].view(np.uint32))
+    # in place (dst == src): k_scale with scale 1 over 701 chunks + a partial one
+    whole = dev.wrap_buffer(a.device_ptr, nbytes)
+    dev.calib_copy(whole, whole, nbytes, encoder=enc)
+    assert np.array_equal(a.map_read(stream=enc).view(np.uint32), x.view(np.uint32))
+
+
 def test_calibration_copy_is_a_copy(gpu, oracle):
     """fwa_calib_copy (the measured-ceiling kernel of bench.py): chunked body + 16-byte tail, byte-exact."""
     fw, dev, queue = gpu

@@ -290,3 +290,60 @@ def test_stream_and_buffer_handles_may_outlive_their_context(gpu, oracle):
     y, _, _ = _run(fw, dev, queue, "Forward", x, 1024)
     mx, _ = oracle.compare(y[:1024], oracle.dft_f64(x[:1024], 1024, -1))
     assert mx <= 1e-5
+
+
+def test_using_a_handle_after_its_context_is_an_error_code_not_a_dangling_pointer(gpu, oracle):
+    """ShardedBatch.destroy() destroys the contexts it created while the caller may still hold
+    buffers, events and encoders on `sb.devices[i]`.  fwa_ctx_destroy detaches every live buffer / event / stream handle of the
+    context, so each later USE answers FWA_ERR_INVALID_ARG (status 1) with a message -- it must not dereference the freed
+    context (`USE_DEVICE(buf->ctx)`) -- and the handles stay destroyable."""
+    fw, dev, queue = gpu
+    n, batch = 4096, 6
+    x = oracle.gen_input(n, batch)
+    sb = fw.ShardedBatch(fw.Forward, n, batch, ordinals=[0, 0])        # two contexts on device 0, created by the object
+    sb.write(x)
+    sb.proc()
+    got = sb.read()
+    d0 = sb.devices[0]
+    L = d0._L
+    mine = d0.create_buffer(n * 8)                 # the caller's own objects on a context the ShardedBatch owns
+    wrapped = d0.wrap_buffer(mine.device_ptr, n * 8)
+    other = dev.create_buffer(n * 8)               # a buffer of a context that stays alive
+    enc = d0.create_command_encoder()
+    ev = fw.Event(d0)
+    ev.record(enc)
+    assert d0.get("live_buffers") >= 3             # slab + mine + wrapped (+ second buffers)
+    sb.destroy()                                   # destroys d0's context underneath `mine`, `wrapped`, `enc`, `ev`
+    assert d0._h is None
+    host = np.zeros(n, dtype=np.complex64)
+    hp = host.ctypes.data_as(ctypes.c_void_p)
+    INVALID = 1
+    calls = {
+        "upload": lambda: L.fwa_buf_upload(mine._h, 0, hp, host.nbytes, None),
+        "download": lambda: L.fwa_buf_download(hp, mine._h, 0, host.nbytes, None),
+        "download_async": lambda: L.fwa_buf_download_async(hp, wrapped._h, 0, host.nbytes, None),
+        "copy_from": lambda: L.fwa_buf_copy(other._h, 0, mine._h, 0, host.nbytes, None),
+        "copy_to": lambda: L.fwa_buf_copy(mine._h, 0, other._h, 0, host.nbytes, None),
+        "fill": lambda: L.fwa_fill_synthetic(mine._h, 1, 0, n, 1.0, None),
+        "calib_copy": lambda: L.fwa_calib_copy(mine._h, other._h, 4096, None),
+        "event_record": lambda: L.fwa_event_record(ev._h, None),
+        "event_sync": lambda: L.fwa_event_synchronize(ev._h),
+        "stream_sync": lambda: L.fwa_stream_synchronize(enc._h),
+    }
+    for name, call in calls.items():
+        assert call() == INVALID, name
+    assert b"context that has been destroyed" in L.fwa_last_error_string(None)
+    # a plan on a LIVE context refuses a buffer of the dead one
+    h = ctypes.c_void_p()
+    assert L.fwa_plan_create(dev._h, 0, n, mine._h, None, ctypes.byref(h)) == INVALID and not h.value
+    assert b"destroyed" in L.fwa_last_error_string(dev._h)
+    # size and pointer are still answered (plain reads of the handle), and every handle can still be freed
+    assert mine.size == n * 8 and wrapped.device_ptr == mine.device_ptr
+    for o in (wrapped, mine, enc):
+        o.destroy()
+    assert L.fwa_event_destroy(ev._h) == 0
+    ev._h = None
+    other.destroy()
+    # the result read before the destroy is the unsharded transform; the surviving context still works
+    y, _, _ = _run(fw, dev, queue, "Forward", x, n)
+    assert np.array_equal(got.view(np.uint32), y.view(np.uint32))
