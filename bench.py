@@ -208,10 +208,10 @@ def config_shapes(fw, dev, queue, enc, checker, reps):
             ang = (-2.0 * np.pi / n) * ((k * p) % n).astype(np.float64)
             ref, kind = np.cos(ang) + 1j * np.sin(ang), f"closed form of a unit impulse at {p}, float64"
         max_rel = float(np.abs(y.astype(np.complex128) - ref).max() / np.abs(ref).max())
-        med = t["idle"][len(t["idle"]) // 2]
+        med = round(t["idle"][len(t["idle"]) // 2], 3)      # the figure the line prints; the rates below derive from it
         out[name] = {"config": what, "fft_len": n, "batch": 1, "plan_path": plan.get("path"), "factors": plan.get("factors"),
                      "launches": plan.get("launches_per_exec"), "execs": reps,
-                     "us_median": round(med, 3), "us_min": round(t["idle"][0], 3), "us_p90": round(t["idle"][(len(t["idle"]) * 9) // 10], 3),
+                     "us_median": med, "us_min": round(t["idle"][0], 3), "us_p90": round(t["idle"][(len(t["idle"]) * 9) // 10], 3),
                      "us_queued_median": round(t["queued"][len(t["queued"]) // 2], 3), "us_queued_min": round(t["queued"][0], 3),
                      "Gsamples_per_s": n / (med * 1e-6) / 1e9,
                      "frac": ALGO_BYTES_PER_SAMPLE * n / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS,
