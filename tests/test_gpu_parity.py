@@ -603,15 +603,15 @@ def test_normalize_and_calibration_copy_on_ragged_grids(gpu, oracle):
     assert out is b
     got = out.map_read(stream=enc)
     assert np.array_equal(got.view(np.uint32), oracle.normalize_ref(x, n).view(np.uint32))
-    # out-of-place calibration copy: 701 whole 64-KiB chunks (k_copy, mapped prefix + plain tail) + a 16-byte-vector tail
-    nbytes = 701 * 65536 + 4096 + 16
-    src = dev.wrap_buffer(a.device_ptr, nbytes)
+    # out-of-place calibration copy of the same bytes: 700 whole 64-KiB chunks (k_copy: mapped prefix of 512 + plain tail of
+    # 188) + 96 16-byte vectors (k_copy_tail)
+    nbytes = x.nbytes
+    assert nbytes // 65536 == 700 and nbytes % 65536 == 1536
     dst = dev.create_buffer(nbytes)
-    dev.calib_copy(dst, src, nbytes, encoder=enc)
-    assert np.array_equal(dst.map_read(stream=enc).view(np.uint32), x[:nbytes // 8].view(np.uint32))
-    # in place (dst == src): k_scale with scale 1 over 701 chunks + a partial one
-    whole = dev.wrap_buffer(a.device_ptr, nbytes)
-    dev.calib_copy(whole, whole, nbytes, encoder=enc)
+    dev.calib_copy(dst, a, nbytes, encoder=enc)
+    assert np.array_equal(dst.map_read(stream=enc).view(np.uint32), x.view(np.uint32))
+    # in place (dst == src): k_scale with scale 1 over 700 chunks + a partial one
+    dev.calib_copy(a, a, nbytes, encoder=enc)
     assert np.array_equal(a.map_read(stream=enc).view(np.uint32), x.view(np.uint32))
 
 
