@@ -332,7 +332,8 @@ def test_using_a_handle_after_its_context_is_an_error_code_not_a_dangling_pointe
     }
     for name, call in calls.items():
         assert call() == INVALID, name
-    assert b"context that has been destroyed" in L.fwa_last_error_string(None)
+        assert b"context has been destroyed" in L.fwa_last_error_string(None) or \
+            b"context that has been destroyed" in L.fwa_last_error_string(None), name
     # a plan on a LIVE context refuses a buffer of the dead one
     h = ctypes.c_void_p()
     assert L.fwa_plan_create(dev._h, 0, n, mine._h, None, ctypes.byref(h)) == INVALID and not h.value
