@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfft_wgpu_amd.so")
 # The laboratory build (`make -C fft_wgpu_amd/csrc lab`): the product library plus the kernel families that measured
-# slower than the defaults (persistent 2^20 ring, L2 teams, 1024-thread 2^20 tiles, LDS radix-2, direct 16-point kernels,
-# the wavefront-shuffle exchange).  Same ABI; only tools/ and the bit-identity tests load it (Device(lab=True)).
+# slower than the defaults and are still cited (the persistent 2^20 ring, the direct 16-point kernels with the wavefront-
+# shuffle exchange) and two test knobs.  Same ABI; only tools/ and the bit-identity tests load it (Device(lab=True)).
 LAB_LIB_PATH = os.environ.get("FWA_LAB_LIBRARY") or os.path.join(_HERE, "libfft_wgpu_amd_lab.so")  # the override is for tools/ A/B builds
 
 FWA_OK = 0

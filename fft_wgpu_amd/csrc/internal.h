@@ -25,7 +25,8 @@
 using fwa::v2f;
 
 // FWA_LAB (libfft_wgpu_amd_lab.so, `make lab`): the same ABI plus the kernel families that measured slower than the
-// shipped ones -- paths 5 and 8, tile_w = 32, small_reg != 1.  The product library rejects those settings.
+// shipped ones -- path 5 (persistent 2^20 ring), small_reg = 2 / 3 (direct 16-point kernels, wavefront-shuffle exchange) --
+// and two test knobs (ring_rotate, inject_launch_failure).  The product library rejects those settings.
 #ifdef FWA_LAB
 constexpr bool kLab = true;
 #else
@@ -33,14 +34,13 @@ constexpr bool kLab = false;
 #endif
 
 enum fwa_path : int64_t {
-    PATH_SMALL = 0,       // n <= 32768: one launch (k_tiny / k_small16 / k_lds_small)
+    PATH_SMALL = 0,       // n <= 32768: one launch (k_chunk / k_small32)
     PATH_TWOPASS_1M = 1,  // n = 2^20: k_p1_1m + k_p2_1m per group of transforms
     PATH_R2_GLOBAL = 2,   // the reference recurrence literally, one launch per stage (forced only)
     PATH_NORMALIZE = 3,
     PATH_IDENTITY = 4,    // n = 1
     PATH_RING_1M = 5,     // n = 2^20: the same two passes as ONE persistent launch with a small ring (k_ring_1m)
-    // n = 2^16 .. 2^18: both passes in one persistent launch, intermediate in one XCD's L2 (k_team)
-    PATH_TEAM = 8,
+    // 8 was the L2-resident team path (k_team, rounds 2-5; removed in round 6: profiles/round6/lab_pruned_families.patch)
     PATH_TILED = 7,       // n = N1*N2[*N3], each 64..1024: 2-3 k_tile passes
 };
 
@@ -51,13 +51,13 @@ namespace fwa_int {
 struct Tables {
     v2f *tw_half = nullptr;   // n/2 entries, processor.rs:43-49 (small / literal paths)
     v2f *tw_inner = nullptr;  // 2^20 path: [k1][n'] = W_1024^{n' k1}
-    v2f *tw_outer[2] = {nullptr, nullptr};  // 2^20 path, tile width 16 / 32: per tile A[32][W], B[32][W]
+    v2f *tw_outer = nullptr;  // 2^20 path: per 16-column tile A[32][16], B[32][16]
     v2f *tw_l[3] = {nullptr, nullptr, nullptr};  // tiled path: per-factor W_L tables
     v2f *tw_lo1 = nullptr, *tw_hi1 = nullptr;    // four-step tables of pass A (domain n)
     v2f *tw_lo_b = nullptr, *tw_hi_b = nullptr;  // four-step tables of pass B (domain N2*N3)
     ~Tables()
     {
-        for (v2f *t : {tw_half, tw_inner, tw_outer[0], tw_outer[1], tw_l[0], tw_l[1], tw_l[2], tw_lo1, tw_hi1, tw_lo_b,
+        for (v2f *t : {tw_half, tw_inner, tw_outer, tw_l[0], tw_l[1], tw_l[2], tw_lo1, tw_hi1, tw_lo_b,
                        tw_hi_b})
             if (t) (void)hipFree(t);
     }
@@ -131,7 +131,6 @@ struct fwa_plan {
     uint64_t ring_bytes = 0;
     int64_t group = 16;            // transforms per launch
     int64_t n_streams = 2;         // internal streams (chains) the groups alternate over
-    int64_t tile_w = 16;           // 2^20 path: columns per tile (16: 512-thread workgroups, 32: 1024-thread)
     // XCD-aware block -> tile mapping (xcd_map bits): -1 = per-path, per-size default (5 on the 2^20 two-pass path;
     // tiled plans: tiled_swizzle_default, plan.cpp)
     int64_t xcd_swizzle = -1;
@@ -142,7 +141,7 @@ struct fwa_plan {
     // laboratory: the ring is this many times larger and the groups rotate through it (same launches, larger cache
     // footprint: prices what the Infinity Cache gives the ring)
     int64_t ring_rotate = 1;
-    // n <= 32768: 1 = k_chunk / k_small32, 3 = direct 16-point kernels, 2 = + wave shuffles, 0 = LDS radix-2
+    // n <= 32768: 1 = k_chunk / k_small32; laboratory: 3 = direct 16-point kernels (16 .. 4096), 2 = + wave shuffles
     int64_t small_reg = 1;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> idone;
@@ -156,8 +155,6 @@ struct fwa_plan {
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
     int64_t ring_slots = 12;       // transforms of intermediate kept (>= depth + 1)
     int64_t wgs = 512;             // persistent workgroups (2 per CU)
-    // L2-resident team pipeline (PATH_TEAM)
-    int64_t max_teams = 0;         // teams (= slabs) per XCD; 0 = as many as fit 3 MiB of an XCD's 4-MiB L2
     // laboratory: the launch of this group fails once (error path of run_groups under test)
     int64_t inject_fail_group = -1;
 };

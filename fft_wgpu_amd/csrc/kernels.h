@@ -63,12 +63,11 @@ hipError_t prepare_tile(uint32_t lg_l, uint32_t cw);
 hipError_t launch_tile(int dir, int mode, uint32_t lg_l, const TileArgs &a, uint64_t batch, hipStream_t st);
 hipError_t setup_small_kernels();
 hipError_t setup_1m_kernels();
-// One pass of the 2^20 pipeline over `n_transforms` transforms; transform i of the launch uses ring slot i.
-// tile_w = 16 (512-thread workgroups, 128-B segments) or 32 (1024-thread workgroups, 256-B segments); the two
-// widths use different ring layouts and tw_outer tables.
-hipError_t launch_p1_1m(int dir, int tile_w, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
+// One pass of the 2^20 pipeline over `n_transforms` transforms; transform i of the launch uses ring slot i
+// (1024 x 16-column tiles: 512-thread workgroups, 128-B segments).
+hipError_t launch_p1_1m(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                         uint32_t n_transforms, uint32_t xcd_swizzle, hipStream_t st);
-hipError_t launch_p2_1m(int dir, int tile_w, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms,
+hipError_t launch_p2_1m(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms,
                         float scale, uint32_t xcd_swizzle, hipStream_t st);
 // 1024-point column pass for n = 1024 * pitch (pitch = 2^4 .. 2^20 columns), matrix layout in and out, four-step
 // twiddle of domain n from the two-level table (tw_lo, tw_hi); transform i at src + i*in_sb / dst + i*out_sb.
@@ -83,36 +82,18 @@ hipError_t launch_spin(uint32_t ticks, uint32_t blocks, hipStream_t st);
 
 #ifdef FWA_LAB
 // ---- laboratory build only (kernels_lab_*.hip): kernel families that measured slower than the shipped ones ----
-hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                            hipStream_t st);
-// 16 <= n <= 16384: register radix-16 Stockham (one launch); src == dst allowed (a transform is read
+// 16 <= n <= 4096: register radix-16 Stockham with direct addressing (one launch); src == dst allowed (a transform is read
 // completely before any of it is written)
 // wave_shuffle: n = 32/64/128 exchange between the two stages with __shfl_xor instead of LDS (opt-in, slower)
 hipError_t launch_small16(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
                           bool wave_shuffle, hipStream_t st);
-// k_team (kernels_tiled.hip): both passes of an n = 2^16 .. 2^18 transform in one persistent launch, intermediate kept
-// in the L2 of one XCD.  slabs = 8 * max_teams * n elements; ctl = team_ctl_bytes() bytes (zeroed per launch; ctl[1] != 0
-// afterwards = a bounded spin timed out).
-bool team_supported(uint32_t lg_n);
-void team_geometry(uint32_t lg_n, uint32_t *team_size, uint32_t *threads, size_t *lds_bytes);
-size_t team_ctl_bytes(uint32_t lg_n, uint32_t max_teams);
-hipError_t prepare_team(uint32_t lg_n);
-hipError_t launch_team(int dir, uint32_t lg_n, const v2f *src, v2f *dst, v2f *slabs, const v2f *tw_a, const v2f *tw_lo,
-                       const v2f *tw_hi, const v2f *tw_c, uint32_t *ctl, uint32_t batch, uint32_t max_teams,
-                       uint32_t n_workgroups, float scale, hipStream_t st);
-// n = 2, 4, 8: whole transforms per thread (in place allowed)
-hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st);
-// Persistent form: one launch per exec, ring of `ring_slots` transforms (>= depth + 1); `ctl` = ring_ctl_bytes(batch)
-// bytes of device memory (zeroed here per call); ctl[1] != 0 afterwards means a bounded spin timed out.
+// Persistent form of the 2^20 pipeline: one launch per exec, ring of `ring_slots` transforms (>= depth + 1); `ctl` =
+// ring_ctl_bytes(batch) bytes of device memory (zeroed here per call); ctl[1] != 0 afterwards means a bounded spin timed out.
 size_t ring_ctl_bytes(uint64_t batch);
 hipError_t launch_ring_1m(int dir, const v2f *src, v2f *dst, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                           uint32_t *ctl, uint32_t batch, uint32_t depth, uint32_t ring_slots, uint32_t n_workgroups,
                           float scale, hipStream_t st);
 hipError_t setup_lab_1m_kernels();
-hipError_t launch_p1_1m_w32(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
-                            uint32_t n_transforms, uint32_t xcd_swizzle, hipStream_t st);
-hipError_t launch_p2_1m_w32(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms, float scale,
-                            uint32_t xcd_swizzle, hipStream_t st);
 #endif
 
 }  // namespace fwa

@@ -108,32 +108,22 @@ hipError_t setup_1m_kernels()
     return e;
 }
 
-// tile_w = 16 ships; the 32-column tile (1024 threads, one workgroup per CU: 23.5 ms against 21.3 at C3) is a laboratory
-// variant (kernels_lab_1m.hip)
-hipError_t launch_p1_1m(int dir, int tile_w, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
+// 1024 x 16-column tiles, 512 threads, two workgroups per CU (the 32-column tile of one 1024-thread workgroup per CU measured
+// 23.5 ms against 21.3 at C3 and left the tree in round 6: profiles/round6/lab_pruned_families.patch)
+hipError_t launch_p1_1m(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
                         uint32_t n_transforms, uint32_t swz, hipStream_t st)
 {
     if (n_transforms == 0) return hipSuccess;
-    if (tile_w == 16)
-        return dir == FWD ? launch_p1_w<FWD, 16>(src, ring, tw_inner, tw_outer, n_transforms, swz, st)
-                          : launch_p1_w<INV, 16>(src, ring, tw_inner, tw_outer, n_transforms, swz, st);
-#ifdef FWA_LAB
-    if (tile_w == 32) return launch_p1_1m_w32(dir, src, ring, tw_inner, tw_outer, n_transforms, swz, st);
-#endif
-    return hipErrorInvalidValue;
+    return dir == FWD ? launch_p1_w<FWD, 16>(src, ring, tw_inner, tw_outer, n_transforms, swz, st)
+                      : launch_p1_w<INV, 16>(src, ring, tw_inner, tw_outer, n_transforms, swz, st);
 }
 
-hipError_t launch_p2_1m(int dir, int tile_w, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms,
+hipError_t launch_p2_1m(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms,
                         float scale, uint32_t swz, hipStream_t st)
 {
     if (n_transforms == 0) return hipSuccess;
-    if (tile_w == 16)
-        return dir == FWD ? launch_p2_w<FWD, 16>(ring, dst, tw_inner, n_transforms, scale, swz, st)
-                          : launch_p2_w<INV, 16>(ring, dst, tw_inner, n_transforms, scale, swz, st);
-#ifdef FWA_LAB
-    if (tile_w == 32) return launch_p2_1m_w32(dir, ring, dst, tw_inner, n_transforms, scale, swz, st);
-#endif
-    return hipErrorInvalidValue;
+    return dir == FWD ? launch_p2_w<FWD, 16>(ring, dst, tw_inner, n_transforms, scale, swz, st)
+                      : launch_p2_w<INV, 16>(ring, dst, tw_inner, n_transforms, scale, swz, st);
 }
 
 }  // namespace fwa

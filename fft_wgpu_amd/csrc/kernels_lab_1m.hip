@@ -1,6 +1,7 @@
-// kernels_lab_1m.hip -- LABORATORY build only (libfft_wgpu_amd_lab.so): variants of the 2^20 pipeline that measured slower
-// than the shipped per-group launches of 1024 x 16 tiles and are kept for A/B timing and bit-identity
-// tests: 32-column tiles (tile_w = 32) and the persistent single-launch ring kernel (path 5).
+// kernels_lab_1m.hip -- LABORATORY build only (libfft_wgpu_amd_lab.so): the persistent single-launch ring form of the 2^20
+// pipeline (path 5), which measured slower than the shipped per-group launches of 1024 x 16 tiles (23.2-24.4 ms against
+// 21.1: DESIGN.md 4, item 2 cites it) and is kept for A/B timing and bit-identity tests.  (The 32-column tile, tile_w = 32,
+// left in round 6: profiles/round6/lab_pruned_families.patch.)
 #include "tile_1m.h"
 
 namespace fwa {
@@ -127,7 +128,7 @@ hipError_t launch_ring_1m(int dir, const v2f *src, v2f *dst, v2f *ring, const v2
 
 hipError_t setup_lab_1m_kernels()
 {
-    hipError_t e = setup_w<32>();
+    hipError_t e = hipSuccess;
     using G = Geom<16>;
     const int lds = G::XCH_BYTES + G::TWI_BYTES + G::TWO_BYTES + 16;
     if (e == hipSuccess)
@@ -135,19 +136,6 @@ hipError_t setup_lab_1m_kernels()
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_1m<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
-}
-
-hipError_t launch_p1_1m_w32(int dir, const v2f *src, v2f *ring, const v2f *tw_inner, const v2f *tw_outer,
-                            uint32_t n_transforms, uint32_t swz, hipStream_t st)
-{
-    return dir == FWD ? launch_p1_w<FWD, 32>(src, ring, tw_inner, tw_outer, n_transforms, swz, st)
-                      : launch_p1_w<INV, 32>(src, ring, tw_inner, tw_outer, n_transforms, swz, st);
-}
-hipError_t launch_p2_1m_w32(int dir, const v2f *ring, v2f *dst, const v2f *tw_inner, uint32_t n_transforms, float scale,
-                            uint32_t swz, hipStream_t st)
-{
-    return dir == FWD ? launch_p2_w<FWD, 32>(ring, dst, tw_inner, n_transforms, scale, swz, st)
-                      : launch_p2_w<INV, 32>(ring, dst, tw_inner, n_transforms, scale, swz, st);
 }
 
 }  // namespace fwa

@@ -1,172 +1,13 @@
-// kernels_lab_small.hip -- LABORATORY build only (libfft_wgpu_amd_lab.so; `make lab`): one-launch kernels that measured
-// slower than the shipped k_chunk (n <= 256) / k_small32 (512 .. 32768) and are kept for A/B timing and bit-identity tests:
-//   k_lds_small  (small_reg = 0)  <- kernel/fft4.wgsl:13-112 staged in LDS as kernel/fft2.wgsl:9-10 intended, radix 2
-//   k_tiny16 / k_tiny2 / k_small16 (small_reg = 3; = 2 adds the wavefront-shuffle exchange at n = 32 / 64 / 128)
+// kernels_lab_small.hip -- LABORATORY build only (libfft_wgpu_amd_lab.so; `make lab`): the one-launch kernel family that
+// measured slower than the shipped k_chunk (n <= 256) / k_small32 (512 .. 32768) and is kept because it holds the
+// wavefront-shuffle butterfly exchange BASELINE.json's north_star names (measured 3-10 % slower than the LDS exchange):
+//   k_small16 (small_reg = 3: direct addressing, 16 points per thread, 16 <= n <= 4096; = 2 adds the `__shfl_xor` exchange
+//   at n = 32 / 64 / 128).
+// Round 6 removed k_lds_small (LDS radix 2), k_tiny16 / k_tiny2 (n < 16) from this file: their only loader was a
+// bit-identity test (profiles/round6/lab_pruned_families.patch is the code as it was).
 #include "device_common.h"
 
 namespace fwa {
-
-// ---------------------------------------------------------------------------
-// small transforms (n <= 4096): whole transforms staged in LDS, all stages in one launch
-// ---------------------------------------------------------------------------
-template <int DIR>
-__global__ __launch_bounds__(256) void k_lds_small(const v2f *__restrict__ src, v2f *__restrict__ dst,
-                                                   const v2f *__restrict__ tw, uint32_t lg_n, uint32_t lg_p,
-                                                   uint64_t batch, float scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t n = 1u << lg_n;
-    const uint32_t P = 1u << lg_p;  // points per workgroup (>= n)
-    v2f *bufA = reinterpret_cast<v2f *>(smem);
-    v2f *bufB = bufA + P;
-    const uint32_t tpb = P >> lg_n;  // transforms per block
-    const uint64_t t0 = (uint64_t)blockIdx.x * tpb;
-    const uint64_t remaining = batch - t0;  // > 0 by grid construction
-    const uint32_t valid = (uint32_t)((remaining < tpb ? remaining : tpb) << lg_n);  // valid points in this block
-    const v2f *g_in = src + t0 * n;
-    v2f *g_out = dst + t0 * n;
-
-    for (uint32_t p = threadIdx.x; p < P; p += 256) bufA[p] = (p < valid) ? g_in[p] : v2f{0.f, 0.f};
-    __syncthreads();
-
-    const uint32_t half = n >> 1;
-    v2f *a = bufA, *b = bufB;
-    for (uint32_t stage = 0; stage < lg_n; ++stage) {
-        const uint32_t J = 1u << stage;
-        for (uint32_t idx = threadIdx.x; idx < (P >> 1); idx += 256) {
-            const uint32_t tl = idx >> (lg_n - 1);
-            const uint32_t i = idx & (half - 1);
-            const uint32_t j = i & (J - 1);
-            const uint32_t sJ = i - j;
-            const uint32_t base = tl << lg_n;
-            const v2f x = a[base + i], y = a[base + i + half];
-            const v2f w = tw[sJ];
-            const uint32_t o1 = base + (sJ << 1) + j;
-            b[o1] = x + y;
-            b[o1 + J] = cmul_tw<DIR>(x - y, w);
-        }
-        __syncthreads();
-        v2f *t = a; a = b; b = t;
-    }
-    for (uint32_t p = threadIdx.x; p < valid; p += 256) g_out[p] = a[p] * scale;
-}
-
-hipError_t launch_lds_small(int dir, const v2f *src, v2f *dst, const v2f *tw, uint32_t n, uint64_t batch, float scale,
-                            hipStream_t st)
-{
-    if (batch == 0) return hipSuccess;
-    uint32_t lg_n = 0;
-    while ((1u << lg_n) < n) ++lg_n;
-    const uint32_t lg_p = lg_n < 11 ? 11 : lg_n;  // 2048 points per block, 4096 for n = 4096
-    const uint32_t tpb = 1u << (lg_p - lg_n);
-    const uint64_t blocks = (batch + tpb - 1) / tpb;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * sizeof(v2f) << lg_p;
-    if (dir == FWD)
-        hipLaunchKernelGGL(k_lds_small<FWD>, dim3((uint32_t)blocks), dim3(256), lds, st, src, dst, tw, lg_n, lg_p, batch,
-                           scale);
-    else
-        hipLaunchKernelGGL(k_lds_small<INV>, dim3((uint32_t)blocks), dim3(256), lds, st, src, dst, tw, lg_n, lg_p, batch,
-                           scale);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// n = 4, 8: each thread owns 16 consecutive samples (16/n whole transforms), one radix-n butterfly
-// network per transform in registers, 16-byte loads and stores.
-// ---------------------------------------------------------------------------
-template <int N, int DIR>
-__global__ __launch_bounds__(256) void k_tiny16(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
-                                              float scale)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
-    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n_samples; base += stride) {
-        v2f x[16];
-        if (base + 16 <= n_samples) {
-            static_for<0, 8>([&](auto i_) {
-                constexpr int i = decltype(i_)::value;
-                const v4f v = *reinterpret_cast<const v4f *>(src + base + 2 * i);
-                x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w};
-            });
-        } else {
-            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; x[i] = (base + i < n_samples) ? src[base + i] : v2f{0.f, 0.f}; });
-        }
-        v2f y[16];
-        static_for<0, 16 / N>([&](auto g_) {
-            constexpr int g = decltype(g_)::value;
-            v2f t[N];
-            static_for<0, N>([&](auto i_) { constexpr int i = decltype(i_)::value; t[i] = x[g * N + i]; });
-            fft_reg<N, DIR>(t);
-            static_for<0, N>([&](auto k_) { constexpr int k = decltype(k_)::value; y[g * N + k] = t[brev<N>(k)] * scale; });
-        });
-        if (base + 16 <= n_samples) {
-            static_for<0, 8>([&](auto i_) {
-                constexpr int i = decltype(i_)::value;
-                *reinterpret_cast<v4f *>(dst + base + 2 * i) = v4f{y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y};
-            });
-        } else {
-            static_for<0, 16>([&](auto i_) { constexpr int i = decltype(i_)::value; if (base + i < n_samples) dst[base + i] = y[i]; });
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// n = 2: one transform = one 16-byte load.  One workgroup per contiguous 64-KiB chunk (the shape of the calibration
-// copy), thread `tid` owns transforms u*256 + tid of the chunk (u < 16): every load and store instruction is fully
-// coalesced and all 16 loads of a thread are in flight before the first butterfly (0.51 -> 0.63 of the roofline).
-// (The same shape with one transform per thread at n >= 4 makes lanes 32+ bytes apart and runs 4-8x slower than
-// k_tiny16 / k_small16: profiles/round2/sweep_tiny_chunk_shape.jsonl.)  Buffer (SRD) addressing: the descriptor ends
-// with the data, so the last chunk needs no bounds code.
-// ---------------------------------------------------------------------------
-template <int DIR>
-__global__ __launch_bounds__(256) void k_tiny2(const v2f *__restrict__ src, v2f *__restrict__ dst, uint64_t n_samples,
-                                               float scale)
-{
-    constexpr uint32_t CHUNK = 65536;  // bytes per workgroup
-    const uint64_t off = (uint64_t)blockIdx.x * CHUNK;
-    const uint64_t left = n_samples * 8 - off;
-    const uint32_t valid = left < CHUNK ? (uint32_t)left : CHUNK;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(const_cast<v2f *>(src)) + off, 0, valid, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(dst) + off, 0, valid, 0x00020000);
-    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-    v4f raw[16];
-    static_for<0, 16>([&](auto u_) {
-        constexpr int u = decltype(u_)::value;
-        raw[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rin, threadIdx.x * 16, u * 4096, AUX_NT));
-    });
-    static_for<0, 16>([&](auto u_) {
-        constexpr int u = decltype(u_)::value;
-        const v2f a = v2f{raw[u].x, raw[u].y}, b = v2f{raw[u].z, raw[u].w};
-        const v2f s = (a + b) * scale, d = (a - b) * scale;  // the 2-point DFT is direction-independent
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v4f{s.x, s.y, d.x, d.y}), rout, threadIdx.x * 16, u * 4096, AUX_NT);
-    });
-}
-
-hipError_t launch_tiny(int dir, const v2f *src, v2f *dst, uint32_t n, uint64_t batch, float scale, hipStream_t st)
-{
-    const uint64_t n_samples = batch * n;
-    if (n_samples == 0) return hipSuccess;
-    if (n == 2) {
-        const uint64_t blocks2 = (n_samples * 8 + 65535) / 65536;
-        if (blocks2 > 0x7fffffffull) return hipErrorInvalidValue;
-        if (dir == FWD) hipLaunchKernelGGL(k_tiny2<FWD>, dim3((uint32_t)blocks2), dim3(256), 0, st, src, dst, n_samples, scale);
-        else hipLaunchKernelGGL(k_tiny2<INV>, dim3((uint32_t)blocks2), dim3(256), 0, st, src, dst, n_samples, scale);
-        return hipGetLastError();
-    }
-    uint64_t blocks = (n_samples / 16 + 255) / 256 + 1;
-    if (blocks > 16384) blocks = 16384;
-    const dim3 g((uint32_t)blocks), b(256);
-#define FWA_TINY(NN)                                                                                        \
-    if (dir == FWD) hipLaunchKernelGGL((k_tiny16<NN, FWD>), g, b, 0, st, src, dst, n_samples, scale);       \
-    else hipLaunchKernelGGL((k_tiny16<NN, INV>), g, b, 0, st, src, dst, n_samples, scale)
-    switch (n) {
-        case 4: FWA_TINY(4); break;
-        case 8: FWA_TINY(8); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef FWA_TINY
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------
 // small transforms, 16 <= n <= 4096: register radix-16 Stockham (the default for n <= 256; from 512 on the plan uses

@@ -5,7 +5,7 @@
 namespace fwa {
 
 // Launchable tile widths: 16 FFTs per workgroup.  (32-wide tiles -- 256-byte segments, workgroups twice as large --
-// measured no faster at any size, profiles/round2/sizes_cw16_vs_cw32.jsonl, and are only instantiated inside k_team.)
+// measured no faster at any size, profiles/round2/sizes_cw16_vs_cw32.jsonl.)
 bool tile_supported(uint32_t lg_l, uint32_t cw) { return cw == 16 && lg_l >= 6 && lg_l <= 10; }
 
 const void *tile_kernel_fwd(int mode, uint32_t lg_l, bool buf, int role)

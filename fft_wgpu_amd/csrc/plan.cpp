@@ -96,12 +96,6 @@ int32_t setup_path(fwa_plan *p)
         if (e != hipSuccess) return fail_hip(ctx, e, "hipFuncSetAttribute(max dynamic LDS)");
         ctx->setup_1m_done = true;
     }
-#ifdef FWA_LAB
-    if (p->path == PATH_TEAM) {
-        hipError_t pe = fwa::prepare_team(p->lg);
-        if (pe != hipSuccess) return fail_hip(ctx, pe, "hipFuncSetAttribute(max dynamic LDS)");
-    }
-#endif
     if (p->path == PATH_TILED) {
         const uint32_t nf = p->lf[2] ? 3 : 2;
         for (uint32_t i = 0; i < nf; ++i)
@@ -125,8 +119,7 @@ int32_t setup_path(fwa_plan *p)
     }
     // tables: shared by every plan of this (length, path, factorisation) on the context
     const uint32_t sig = p->lf[0] | (p->lf[1] << 8) | (p->lf[2] << 16);
-    const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M
-                                              : (p->path == PATH_TEAM ? (int64_t)PATH_TILED : p->path), sig);
+    const auto key = std::make_tuple(fft_len, p->path == PATH_RING_1M ? (int64_t)PATH_TWOPASS_1M : p->path, sig);
     // The tables of the NEW path / factorisation are held locally and handed to the plan only once its pipeline has
     // been built: a failed re-tune (e.g. no memory for the new ring) leaves the plan with the tables of the factors it
     // keeps (the callers restore path and factors).
@@ -152,7 +145,7 @@ int32_t setup_path(fwa_plan *p)
         st = build_pipeline(p, g, default_chains(p->batch, g));
     } else if (p->path == PATH_TWOPASS_1M) {
         st = build_pipeline(p, 16, default_chains(p->batch, 16));  // 16 transforms = 1024 tiles per launch
-    } else if (p->path == PATH_RING_1M || p->path == PATH_TEAM) {
+    } else if (p->path == PATH_RING_1M) {
         st = build_pipeline(p, 0, 0);
     }
     if (st) return st;
@@ -163,7 +156,6 @@ int32_t setup_path(fwa_plan *p)
 size_t ctl_bytes(const fwa_plan *p)
 {
 #ifdef FWA_LAB
-    if (p->path == PATH_TEAM) return fwa::team_ctl_bytes(p->lg, (uint32_t)p->max_teams);
     return fwa::ring_ctl_bytes(p->batch);
 #else
     (void)p;
@@ -227,6 +219,150 @@ static int32_t run_groups(fwa_plan *plan, hipStream_t st, Body body)
     if (e != hipSuccess) return fail_hip(ctx, e, "kernel launch", FWA_ERR_LAUNCH);
     if (je != hipSuccess) return fail_hip(ctx, je, "hipEventRecord/hipStreamWaitEvent (join of the chain streams)");
     return FWA_OK;
+}
+
+
+// ---- the tiled path (PATH_TILED): n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3) ----
+//   pass A: FFT over n1 (columns, four-step twiddle W_n), user buffer -> ring slab
+//   pass B: FFT over n2 per k1 (columns, twiddle W_{N2*N3}), in place in the slab            [three factors only]
+//   pass C: FFT over the contiguous axis with the transposed store, slab -> result buffer
+// What the passes of one exec share: factor sizes, the block -> tile map and the slab layout pass A leaves for pass C.
+struct TiledShape {
+    uint64_t N, N1, N2, N3;
+    bool three;
+    uint32_t swizzle;   // xcd_map bits handed to every kernel
+    // k_colsw writes the slab tile-contiguously ([tile][k1][ring_cw]) when the last pass (k_rows32) can read that layout
+    // back; 0 = matrix layout
+    uint32_t ring_cw;
+};
+
+// One pass of a tiled exec: which kernel, and every launch argument except the group's pointers and transform count.
+// Built once per fwa_plan_exec by pass_a / pass_b / pass_c, immutable afterwards, called once per group.
+struct TiledPass {
+    enum Kernel { NONE, COLSW, COLS32, P1_GEN, TILE_COLS_K, ROWS32, TILE_ROWS_K } kernel = NONE;
+    int dir = fwa::FWD;
+    uint32_t lg_l = 0;                 // log2 of this pass's FFT length
+    const v2f *tw = nullptr, *tw_lo = nullptr, *tw_hi = nullptr;
+    uint32_t pitch = 0;                // columns of the n1 x pitch matrix (COLSW, COLS32, P1_GEN)
+    uint32_t n1 = 0;                   // ROWS32: rows of the matrix
+    uint64_t sb = 0;                   // elements between transforms, in and out
+    float scale = 1.0f;
+    uint32_t swizzle = 0, ring_cw = 0;
+    fwa::TileArgs ta{};                // TILE_COLS_K / TILE_ROWS_K: complete except in / out
+    hipError_t operator()(const v2f *in, v2f *out, uint64_t cnt, hipStream_t s) const
+    {
+        switch (kernel) {
+            case COLSW:
+                return fwa::launch_colsw(dir, lg_l, true, ring_cw != 0, in, out, tw, tw_lo, tw_hi, pitch, sb, sb,
+                                         (uint32_t)cnt, swizzle, s);
+            case COLS32:
+                return fwa::launch_cols32(dir, lg_l, true, in, out, tw, tw_lo, tw_hi, pitch, sb, sb, (uint32_t)cnt,
+                                          swizzle, s);
+            case P1_GEN:
+                return fwa::launch_p1_gen(dir, true, in, out, tw, tw_lo, tw_hi, pitch, sb, sb, (uint32_t)cnt, swizzle, s);
+            case ROWS32:
+                return fwa::launch_rows32(dir, lg_l, in, out, tw, n1, sb, sb, (uint32_t)cnt, scale, swizzle, ring_cw, s);
+            case TILE_COLS_K:
+            case TILE_ROWS_K: {
+                fwa::TileArgs t = ta;
+                t.in = in; t.out = out;
+                return fwa::launch_tile(dir, kernel == TILE_COLS_K ? fwa::TILE_COLS : fwa::TILE_ROWS_T, lg_l, t, cnt, s);
+            }
+            case NONE: break;
+        }
+        return hipSuccess;
+    }
+};
+
+static bool tiled_uses_colsw(const fwa_plan *p)
+{
+    return p->colsw && fwa::colsw_supported(p->lf[0]) && p->lg <= 28;
+}
+
+static TiledShape tiled_shape(const fwa_plan *p)
+{
+    TiledShape sh{};
+    sh.three = p->lf[2] != 0;
+    sh.N = p->n;
+    sh.N1 = 1ull << p->lf[0]; sh.N2 = 1ull << p->lf[1]; sh.N3 = sh.three ? (1ull << p->lf[2]) : 1;
+    sh.swizzle = p->xcd_swizzle < 0 ? tiled_swizzle_default(p) : (uint32_t)p->xcd_swizzle;
+    const bool ring = tiled_uses_colsw(p) && p->tile_ring && !sh.three
+        && fwa::rows32_ring_supported(p->lf[1], fwa::colsw_width(p->lf[0]));
+    sh.ring_cw = ring ? fwa::colsw_width(p->lf[0]) : 0u;
+    return sh;
+}
+
+// pass A: columns of length N1 at pitch N / N1, user buffer -> slab
+static TiledPass pass_a(const fwa_plan *p, const TiledShape &sh, const Tables &tb, int dir)
+{
+    TiledPass ps;
+    ps.dir = dir; ps.lg_l = p->lf[0]; ps.sb = sh.N; ps.swizzle = sh.swizzle; ps.ring_cw = sh.ring_cw;
+    ps.pitch = (uint32_t)(sh.N / sh.N1);
+    ps.tw = tb.tw_l[0]; ps.tw_lo = tb.tw_lo1; ps.tw_hi = tb.tw_hi1;
+    ps.kernel = tiled_uses_colsw(p)                             ? TiledPass::COLSW     // 256 x 64 / 512 x 32 column tiles
+                : p->lf[0] > 10                                  ? TiledPass::COLS32    // 2048-point columns
+                : (p->lf[0] == 10 && p->p1_gen && tb.tw_inner)   ? TiledPass::P1_GEN    // the 2^20 column kernel at run-time pitch
+                                                                 : TiledPass::TILE_COLS_K;
+    switch (ps.kernel) {
+        case TiledPass::P1_GEN:
+            ps.tw = tb.tw_inner;
+            break;
+        case TiledPass::TILE_COLS_K: {
+            const uint32_t cw = pass_cw(p, 0);
+            fwa::TileArgs &t = ps.ta;
+            t.tw = tb.tw_l[0]; t.tw_lo = tb.tw_lo1; t.tw_hi = tb.tw_hi1;
+            t.scale = 1.0f; t.cw = cw; t.role = fwa::ROLE_FIRST; t.xcd_swizzle = sh.swizzle;
+            t.in_sb = t.out_sb = sh.N; t.in_s1 = t.out_s1 = 0; t.in_st = t.out_st = cw;
+            t.pitch = sh.N / sh.N1; t.out_stride = 0; t.d1_count = 1; t.tile_count = (uint32_t)(sh.N / sh.N1 / cw);
+            break;
+        }
+        default: break;
+    }
+    return ps;
+}
+
+// pass B (three factors): columns of length N2 at pitch N3 inside every k1-plane, in place in the slab
+static TiledPass pass_b(const fwa_plan *p, const TiledShape &sh, const Tables &tb, int dir)
+{
+    TiledPass ps;
+    if (!sh.three) return ps;   // kernel == NONE
+    ps.kernel = TiledPass::TILE_COLS_K;
+    ps.dir = dir; ps.lg_l = p->lf[1];
+    const uint32_t cw = pass_cw(p, 1);
+    fwa::TileArgs &t = ps.ta;
+    t.tw = tb.tw_l[1]; t.tw_lo = tb.tw_lo_b; t.tw_hi = tb.tw_hi_b;
+    t.scale = 1.0f; t.cw = cw; t.role = fwa::ROLE_MIDDLE; t.xcd_swizzle = sh.swizzle;
+    t.in_sb = t.out_sb = sh.N; t.in_s1 = t.out_s1 = sh.N2 * sh.N3; t.in_st = t.out_st = cw;
+    t.pitch = sh.N3; t.out_stride = 0; t.d1_count = (uint32_t)sh.N1; t.tile_count = (uint32_t)(sh.N3 / cw);
+    return ps;
+}
+
+// pass C: rows of the last axis, adjacent k1 per tile, transposed store into the result buffer (+ the 1/n of Inverse)
+static TiledPass pass_c(const fwa_plan *p, const TiledShape &sh, const Tables &tb, int dir, float scale)
+{
+    TiledPass ps;
+    const uint32_t li = sh.three ? 2 : 1;
+    ps.dir = dir; ps.lg_l = p->lf[li]; ps.sb = sh.N; ps.scale = scale; ps.swizzle = sh.swizzle; ps.ring_cw = sh.ring_cw;
+    ps.tw = tb.tw_l[li]; ps.n1 = (uint32_t)sh.N1;
+    const bool rows32 = !sh.three && p->lg <= 28 && fwa::rows32_supported(p->lf[1])
+        && (p->rows32 || p->lf[1] > 10 || sh.ring_cw);   // 2048 / 4096-point rows and the tile ring exist only there
+    ps.kernel = rows32 ? TiledPass::ROWS32 : TiledPass::TILE_ROWS_K;
+    switch (ps.kernel) {
+        case TiledPass::TILE_ROWS_K: {
+            const uint32_t cw = pass_cw(p, li);
+            fwa::TileArgs &t = ps.ta;
+            t.tw = tb.tw_l[li]; t.tw_lo = nullptr; t.tw_hi = nullptr;
+            t.scale = scale; t.cw = cw; t.role = fwa::ROLE_LAST; t.xcd_swizzle = sh.swizzle;
+            t.in_sb = t.out_sb = sh.N;
+            t.pitch = sh.N / sh.N1;  // distance between the rows k1 and k1 + 1
+            t.in_st = cw * (sh.N / sh.N1); t.out_st = cw; t.tile_count = (uint32_t)(sh.N1 / cw);
+            if (sh.three) { t.d1_count = (uint32_t)sh.N2; t.in_s1 = sh.N3; t.out_s1 = sh.N1; t.out_stride = sh.N1 * sh.N2; }
+            else { t.d1_count = 1; t.in_s1 = t.out_s1 = 0; t.out_stride = sh.N1; }
+            break;
+        }
+        default: break;
+    }
+    return ps;
 }
 
 
@@ -390,17 +526,10 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             break;
         case PATH_SMALL:
 #ifdef FWA_LAB
-            // laboratory kernels (A/B): direct 16-point kernels, shuffle exchange, LDS radix 2
-            if (plan->small_reg != 1) {
-                if (plan->small_reg && plan->n < 16)
-                    e = fwa::launch_tiny(dir, a, out, plan->n, plan->batch, scale, st);
-                else if (plan->small_reg && plan->n >= 512 && (plan->small_reg != 3 || plan->n > 4096))
-                    e = fwa::launch_small32(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
-                else if (plan->small_reg)
-                    e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2,
-                                            st);
-                else
-                    e = fwa::launch_lds_small(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, st);
+            // laboratory kernels (A/B): the direct 16-point kernels (small_reg = 3, 16 <= n <= 4096), with the
+            // wavefront-shuffle exchange at 32 / 64 / 128 (small_reg = 2, which leaves n >= 512 to k_small32)
+            if (plan->small_reg != 1 && plan->n >= 16 && plan->n <= 4096 && (plan->small_reg == 3 || plan->n < 512)) {
+                e = fwa::launch_small16(dir, a, out, tb.tw_half, plan->n, plan->batch, scale, plan->small_reg == 2, st);
                 break;
             }
 #endif
@@ -421,8 +550,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
         }
         case PATH_TWOPASS_1M: {
             // in place at group granularity: 2^20 has even log2, the result buffer is src (processor.rs:153-157)
-            const int w = (int)plan->tile_w;
-            const v2f *two = tb.tw_outer[w == 32 ? 1 : 0];
+            const v2f *two = tb.tw_outer;
             // default: XCD-contiguous tiles + adjacent tiles on the two residents of a CU (bit 2: + 4-8 % for
             // launches that have the chip to themselves, + 0.6 % with two chains in flight: tile_1m.h xcd_block,
             // profiles/round4/sweep_pair_map_two_chains.jsonl)
@@ -433,9 +561,9 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 const uint64_t round = g / (plan->istreams.empty() ? 1 : plan->istreams.size());
                 v2f *slab = plan->ring + (round % (uint64_t)plan->ring_rotate) *
                                              (uint64_t)plan->n_streams * G * N + (uint64_t)c * G * N;
-                hipError_t le = fwa::launch_p1_1m(dir, w, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt, swz, s);
+                hipError_t le = fwa::launch_p1_1m(dir, a + g * G * N, slab, tb.tw_inner, two, (uint32_t)cnt, swz, s);
                 if (le != hipSuccess) return le;
-                return fwa::launch_p2_1m(dir, w, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale, swz, s);
+                return fwa::launch_p2_1m(dir, slab, out + g * G * N, tb.tw_inner, (uint32_t)cnt, scale, swz, s);
             });
         }
 #ifdef FWA_LAB
@@ -444,85 +572,27 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
                 return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no scratch ring (a failed re-tune?)");
             const uint64_t slots = (uint64_t)plan->ring_slots < plan->batch ? (uint64_t)plan->ring_slots : plan->batch;
             const uint64_t depth = (uint64_t)plan->depth < slots ? (uint64_t)plan->depth : (slots > 1 ? slots - 1 : 1);
-            e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer[0], plan->ring_ctl,
+            e = fwa::launch_ring_1m(dir, a, out, plan->ring, tb.tw_inner, tb.tw_outer, plan->ring_ctl,
                                     (uint32_t)plan->batch,
                                     (uint32_t)depth, (uint32_t)(slots > depth ? slots : depth + 1),
                                         (uint32_t)plan->wgs, scale, st);
             break;
         }
-        case PATH_TEAM: {
-            if (!plan->ring || !plan->ring_ctl)
-                return fail(ctx, FWA_ERR_INVALID_ARG, "plan has no team slabs (a failed re-tune?)");
-            e = fwa::launch_team(dir, plan->lg, a, out, plan->ring, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1, tb.tw_l[1],
-                                 plan->ring_ctl,
-                                 (uint32_t)plan->batch, (uint32_t)plan->max_teams, (uint32_t)plan->wgs, scale, st);
-            break;
-        }
 #endif
         case PATH_TILED: {
-            // n = N1*N2[*N3]; index n = (n1*N2 + n2)*N3 + n3, k = k1 + N1*(k2 + N2*k3).  Per group of transforms:
-            // pass A: FFT over n1 (cols, twiddle W_n), user buffer -> ring slab; [pass B: FFT over n2 per k1 (cols,
-            // twiddle W_{N2*N3}), in place in the slab]; pass C: FFT over the contiguous axis with the transposed
-            // store, slab -> result buffer (src for even log2 n -- in place at group granularity -- else second).
-            const bool three = plan->lf[2] != 0;
-            const uint64_t N1 = 1ull << plan->lf[0], N2 = 1ull << plan->lf[1], N3 = three ? (1ull << plan->lf[2]) : 1;
+            // Per group of transforms: pass A, user buffer -> ring slab; [pass B, in place in the slab]; pass C, slab ->
+            // result buffer (src for even log2 n -- in place at group granularity -- else second).  The three passes are
+            // built once per exec (TiledPass above: kernel choice + launch arguments, nothing on the heap) and only
+            // receive the group's pointers here.
+            const TiledShape shape = tiled_shape(plan);
+            const TiledPass pa = pass_a(plan, shape, tb, dir), pb = pass_b(plan, shape, tb, dir),
+                            pc = pass_c(plan, shape, tb, dir, scale);
             return run_groups(plan, st, [&](uint64_t g, uint64_t cnt, hipStream_t s, size_t c) {
                 v2f *slab = plan->ring + (uint64_t)c * G * N;
-                fwa::TileArgs ta{};
-                ta.xcd_swizzle = plan->xcd_swizzle < 0 ? tiled_swizzle_default(plan) : (uint32_t)plan->xcd_swizzle;
-                // pass A
-                uint32_t cw = pass_cw(plan, 0);
-                ta.in = a + g * G * N; ta.out = slab; ta.tw = tb.tw_l[0]; ta.tw_lo = tb.tw_lo1; ta.tw_hi = tb.tw_hi1;
-                ta.scale = 1.0f; ta.cw = cw; ta.role = fwa::ROLE_FIRST;
-                ta.in_sb = ta.out_sb = N; ta.in_s1 = ta.out_s1 = 0; ta.in_st = ta.out_st = cw;
-                ta.pitch = N / N1; ta.out_stride = 0; ta.d1_count = 1; ta.tile_count = (uint32_t)(N / N1 / cw);
-                hipError_t le;
-                // k_colsw writes the slab tile-contiguously when the last pass (k_rows32) can read that layout back
-                const bool use_colsw = plan->colsw && fwa::colsw_supported(plan->lf[0]) && plan->lg <= 28;
-                const uint32_t ring_cw = (use_colsw && plan->tile_ring && !three
-                                          && fwa::rows32_ring_supported(plan->lf[1], fwa::colsw_width(plan->lf[0])))
-                                             ? fwa::colsw_width(plan->lf[0]) : 0u;
-                if (use_colsw)
-                    le = fwa::launch_colsw(dir, plan->lf[0], true, ring_cw != 0, ta.in, slab, tb.tw_l[0], tb.tw_lo1,
-                                           tb.tw_hi1, (uint32_t)(N / N1),
-                                           N, N, (uint32_t)cnt, ta.xcd_swizzle, s);
-                else if (plan->lf[0] > 10)
-                    le = fwa::launch_cols32(dir, plan->lf[0], true, ta.in, slab, tb.tw_l[0], tb.tw_lo1, tb.tw_hi1,
-                                            (uint32_t)(N / N1), N,
-                                            N, (uint32_t)cnt, ta.xcd_swizzle, s);
-                else if (plan->lf[0] == 10 && plan->p1_gen && tb.tw_inner)
-                    le = fwa::launch_p1_gen(dir, true, ta.in, slab, tb.tw_inner, tb.tw_lo1, tb.tw_hi1,
-                                            (uint32_t)(N / N1), N, N,
-                                            (uint32_t)cnt, ta.xcd_swizzle, s);
-                else
-                    le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[0], ta, cnt, s);
-                if (le != hipSuccess) return le;
-                if (three) {  // pass B, in place in the slab
-                    cw = pass_cw(plan, 1);
-                    if (N3 < cw) cw = 16;
-                    ta.in = slab; ta.out = slab; ta.tw = tb.tw_l[1]; ta.tw_lo = tb.tw_lo_b; ta.tw_hi = tb.tw_hi_b;
-                    ta.cw = cw; ta.role = fwa::ROLE_MIDDLE; ta.in_st = ta.out_st = cw;
-                    ta.in_s1 = ta.out_s1 = N2 * N3; ta.pitch = N3; ta.d1_count = (uint32_t)N1;
-                    ta.tile_count = (uint32_t)(N3 / cw);
-                    le = fwa::launch_tile(dir, fwa::TILE_COLS, plan->lf[1], ta, cnt, s);
-                    if (le != hipSuccess) return le;
-                }
-                // pass C: rows of the last axis, cw adjacent k1 per tile
-                if (!three && plan->lg <= 28 && fwa::rows32_supported(plan->lf[1])
-                    && (plan->rows32 || plan->lf[1] > 10 || ring_cw))
-                    return fwa::launch_rows32(dir, plan->lf[1], slab, out + g * G * N, tb.tw_l[1], (uint32_t)N1, N, N,
-                                              (uint32_t)cnt,
-                                              scale, ta.xcd_swizzle, ring_cw, s);
-                const uint32_t li = three ? 2 : 1;
-                cw = pass_cw(plan, li);
-                ta.in = slab; ta.out = out + g * G * N; ta.tw = tb.tw_l[li]; ta.tw_lo = nullptr; ta.tw_hi = nullptr;
-                ta.scale = scale; ta.cw = cw; ta.role = fwa::ROLE_LAST;
-                ta.in_sb = ta.out_sb = N;
-                ta.pitch = N / N1;  // distance between the rows k1 and k1+1
-                ta.in_st = cw * (N / N1); ta.out_st = cw; ta.tile_count = (uint32_t)(N1 / cw);
-                if (three) { ta.d1_count = (uint32_t)N2; ta.in_s1 = N3; ta.out_s1 = N1; ta.out_stride = N1 * N2; }
-                else { ta.d1_count = 1; ta.in_s1 = ta.out_s1 = 0; ta.out_stride = N1; }
-                return fwa::launch_tile(dir, fwa::TILE_ROWS_T, plan->lf[li], ta, cnt, s);
+                hipError_t le = pa(a + g * G * N, slab, cnt, s);
+                if (le == hipSuccess && pb.kernel != TiledPass::NONE) le = pb(slab, slab, cnt, s);
+                if (le == hipSuccess) le = pc(slab, out + g * G * N, cnt, s);
+                return le;
             });
         }
         default:

@@ -62,8 +62,8 @@ int32_t build_tables(fwa_ctx *ctx, uint32_t n, int64_t path, const uint32_t lf[3
             for (uint32_t q = 0; q < 32; ++q) inner[k1 * 32 + q] = tw_f64((uint64_t)k1 * q, 1024);
         st = upload_table(ctx, inner, &t->tw_inner);
         const uint64_t N = 1ull << 20;
-        for (int wi = 0; wi < (kLab ? 2 : 1) && !st; ++wi) {
-            const uint32_t W = wi ? 32 : 16, tiles = 1024 / W;
+        for (int wi = 0; wi < 1 && !st; ++wi) {   // one tile width ships: 16 columns
+            const uint32_t W = 16, tiles = 1024 / W;
             std::vector<v2f> outer((size_t)tiles * 64 * W);
             for (uint32_t tile = 0; tile < tiles; ++tile)
                 for (uint32_t k = 0; k < 32; ++k)
@@ -72,7 +72,7 @@ int32_t build_tables(fwa_ctx *ctx, uint32_t n, int64_t path, const uint32_t lf[3
                         outer[(size_t)tile * 64 * W + k * W + c] = tw_f64(n2 * k, N);                // A[k1][c]
                         outer[(size_t)tile * 64 * W + 32 * W + k * W + c] = tw_f64(32 * n2 * k, N);  // B[k2][c]
                     }
-            st = upload_table(ctx, outer, &t->tw_outer[wi]);
+            st = upload_table(ctx, outer, &t->tw_outer);
         }
         return st;
     }
@@ -165,33 +165,6 @@ int32_t build_pipeline(fwa_plan *p, int64_t group, int64_t n_streams)
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::ring_ctl_bytes(p->batch));
             if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e,
                 "hipMalloc(ring control)"); }
-        }
-        Pipeline old = take_pipeline(p);
-        destroy_pipeline_objects(ctx, old, true);
-        if (p->ring_ctl) (void)hipFree(p->ring_ctl);
-        p->ring_ctl = ctl;
-        p->ring = pl.ring; p->ring_bytes = pl.ring_bytes;
-        return FWA_OK;
-    }
-    if (p->path == PATH_TEAM) {
-        uint32_t ts = 0, th = 0;
-        size_t lds = 0;
-        fwa::team_geometry(p->lg, &ts, &th, &lds);
-        const uint64_t slab = (uint64_t)p->n * sizeof(v2f);
-        if (p->max_teams <= 0) p->max_teams = (int64_t)((3ull << 20) / slab ? (3ull << 20) / slab : 1);
-        const uint64_t need_teams = (p->batch + 7) / 8;  // more teams than transforms per XCD are useless
-        if ((uint64_t)p->max_teams > need_teams && need_teams) p->max_teams = (int64_t)need_teams;
-        p->wgs = 8 * p->max_teams * (int64_t)ts;
-        Pipeline pl;
-        pl.ring_bytes = p->batch ? 8ull * (uint64_t)p->max_teams * slab : 0;
-        uint32_t *ctl = nullptr;
-        if (pl.ring_bytes) {
-            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.ring), pl.ring_bytes);
-            if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc(team slabs)");
-            ++ctx->n_ring_allocs;
-            e = hipMalloc(reinterpret_cast<void **>(&ctl), fwa::team_ctl_bytes(p->lg, (uint32_t)p->max_teams));
-            if (e != hipSuccess) { destroy_pipeline_objects(ctx, pl, false); return fail_hip(ctx, e,
-                "hipMalloc(team control)"); }
         }
         Pipeline old = take_pipeline(p);
         destroy_pipeline_objects(ctx, old, true);

@@ -1,4 +1,4 @@
-// tile_body.h -- the tile of the multi-pass paths (shared by kernels_tiled.hip: k_tile and kernels_team.hip: k_team).
+// tile_body.h -- the tile of the multi-pass paths (kernels_tiled.hip: k_tile).
 #pragma once
 #include "device_common.h"
 

@@ -25,7 +25,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "path") *value = plan->path;
     else if (k == "group") *value = plan->group;
     else if (k == "streams") *value = plan->n_streams;
-    else if (k == "tile_w") *value = plan->tile_w;
+    else if (k == "tile_w") *value = 16;   // one tile width ships (kept as a key: bench lines of every round carry it)
     else if (k == "xcd_swizzle") {
         const int64_t dflt = plan->path == PATH_TWOPASS_1M ? 5
                              : (plan->path == PATH_TILED ? (int64_t)tiled_swizzle_default(plan) : 0);
@@ -34,7 +34,6 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "depth") *value = plan->depth;
     else if (k == "ring_slots") *value = plan->ring_slots;
     else if (k == "wgs") *value = plan->wgs;
-    else if (k == "max_teams") *value = plan->max_teams;
     else if (k == "device_error") {
         // bounded-spin timeout flag of the persistent kernel (0 in every healthy run); synchronises the device
         *value = 0;
@@ -60,7 +59,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     else if (k == "launches_per_exec") {
         switch (plan->path) {
             case PATH_TWOPASS_1M: *value = 2 * ng; break;
-            case PATH_RING_1M: case PATH_TEAM: *value = 1; break;
+            case PATH_RING_1M: *value = 1; break;
             case PATH_TILED: *value = (plan->lf[2] ? 3 : 2) * ng; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
@@ -108,32 +107,10 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
     if (k == "tile_w") {
         if (plan->path != PATH_TWOPASS_1M)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the 2^20 two-pass path");
-        if (value != 16 && value != 32) return fail(ctx, FWA_ERR_INVALID_ARG, "tile_w is 16 or 32");
-        if (value == 32 && !kLab)
-            return fail(ctx, FWA_ERR_UNSUPPORTED, "tile_w = 32 is a laboratory variant (libfft_wgpu_amd_lab.so)");
-        plan->tile_w = value;
+        if (value != 16) return fail(ctx, FWA_ERR_UNSUPPORTED, "tile_w is 16 (the 32-column tile left the tree in round 6)");
         return FWA_OK;
     }
-#ifdef FWA_LAB
-    if (k == "max_teams" || (k == "wgs" && plan->path == PATH_TEAM)) {
-        if (plan->path != PATH_TEAM) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the team path");
-        if (value < 1 || value > 65536) return fail(ctx, FWA_ERR_INVALID_ARG, "value out of range");
-        if (k == "wgs") {
-            // a team only forms from workgroups of ONE XCD and blocks are dealt round-robin over the 8 XCDs: fewer than
-            // 8 x team size workgroups may leave every XCD short of a team and the launch would transform nothing
-            uint32_t ts = 0, th = 0;
-            size_t lds = 0;
-            fwa::team_geometry(plan->lg, &ts, &th, &lds);
-            if (value < 8 * (int64_t)ts)
-                return fail(ctx, FWA_ERR_INVALID_ARG, "wgs must be at least 8 x the team size");
-            plan->wgs = value;
-            return FWA_OK;
-        }
-        plan->max_teams = value;
-        return build_pipeline(plan, 0, 0);
-    }
-#endif
-    if (k == "max_teams" || k == "depth" || k == "ring_slots" || k == "wgs") {
+    if (k == "depth" || k == "ring_slots" || k == "wgs") {
         if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "key belongs to a laboratory path (libfft_wgpu_amd_lab.so)");
         if (plan->path != PATH_RING_1M)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to the persistent 2^20 path");
@@ -190,17 +167,17 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         if (plan->path != PATH_SMALL) return fail(ctx, FWA_ERR_UNSUPPORTED, "key only applies to n <= 32768");
         if (value != 1 && !kLab)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "small_reg != 1 selects laboratory kernels (libfft_wgpu_amd_lab.so)");
-        if (!value && plan->n > 4096) return fail(ctx, FWA_ERR_UNSUPPORTED, "the LDS radix-2 kernel stops at n = 4096");
-        // 1: k_chunk (4 .. 256) and k_small32 (from 512), the default; 3: the direct-addressing kernels k_tiny16 /
-        // k_small16 up to 4096 (A/B); 2: as 3 with the wavefront-shuffle exchange at n = 32/64/128; 0: LDS radix 2
-        plan->small_reg = (value >= 0 && value <= 3) ? value : 1;
+        // 1: k_chunk (2 .. 256) and k_small32 (from 512), the default; 3: the direct-addressing kernel k_small16 at
+        // 16 .. 4096 (A/B); 2: as 3 up to 256 with the wavefront-shuffle exchange at n = 32 / 64 / 128
+        if (value < 1 || value > 3) return fail(ctx, FWA_ERR_INVALID_ARG, "small_reg is 1, 2 or 3");
+        plan->small_reg = value;
         return FWA_OK;
     }
     if (k == "path") {
         if (plan->kind == FWA_NORMALIZE) return fail(ctx, FWA_ERR_UNSUPPORTED, "normalize has one path");
         if (value == plan->path) return FWA_OK;
-        if ((value == PATH_RING_1M || value == PATH_TEAM) && !kLab)
-            return fail(ctx, FWA_ERR_UNSUPPORTED, "paths 5 and 8 are laboratory paths (libfft_wgpu_amd_lab.so)");
+        if (value == PATH_RING_1M && !kLab)
+            return fail(ctx, FWA_ERR_UNSUPPORTED, "path 5 is a laboratory path (libfft_wgpu_amd_lab.so)");
         if ((value == PATH_RING_1M || value == PATH_TWOPASS_1M)
             && (plan->path == PATH_RING_1M || plan->path == PATH_TWOPASS_1M)) {
             // the two forms of the 2^20 pipeline: per-group launches with a large ring, or one persistent launch
@@ -209,24 +186,6 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
             const int32_t st = setup_path(plan);
             if (st) plan->path = old;
             if (!st && value == PATH_TWOPASS_1M
-                && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
-            return st;
-        }
-        if ((value == PATH_TEAM || value == PATH_TILED) && (plan->path == PATH_TEAM || plan->path == PATH_TILED)) {
-#ifdef FWA_LAB
-            if (value == PATH_TEAM && !fwa::team_supported(plan->lg))
-                return fail(ctx, FWA_ERR_UNSUPPORTED, "the team path covers n = 2^16 .. 2^18");
-#endif
-            const int64_t old = plan->path;
-            uint32_t old_lf[3] = {plan->lf[0], plan->lf[1], plan->lf[2]};
-            plan->path = value;
-            if (value == PATH_TEAM) {
-                plan->lf[0] = plan->lg / 2; plan->lf[1] = plan->lg - plan->lf[0]; plan->lf[2] = 0;
-            }
-            else { bool cw = false; (void)choose_path(plan->n, plan->batch, plan->lf, &cw); plan->colsw = cw; }
-            const int32_t st = setup_path(plan);
-            if (st) { plan->path = old; plan->lf[0] = old_lf[0]; plan->lf[1] = old_lf[1]; plan->lf[2] = old_lf[2]; }
-            if (!st && value == PATH_TILED
                 && plan->ring_ctl) { (void)hipFree(plan->ring_ctl); plan->ring_ctl = nullptr; }
             return st;
         }

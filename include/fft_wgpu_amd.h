@@ -212,12 +212,12 @@ int32_t fwa_describe_path(uint32_t fft_len, int32_t *path, uint32_t log2_factors
  * answers FWA_ERR_UNSUPPORTED): kernel families that measured slower than the shipped ones, kept for A/B timing and
  * bit-identity tests --
  *   "path" 5 (the 2^20 pipeline as ONE persistent launch with a small ring; 1 <-> 5 at 2^20) with "depth", "ring_slots",
- *   "wgs"; "path" 8 (both passes of a 2^16..2^18 transform in one persistent launch, intermediate in one XCD's L2;
- *   7 <-> 8) with "max_teams", "wgs" (>= 8 x team size); "device_error" (paths 5, 8; synchronises the device; non-zero
- *   = a bounded in-kernel spin timed out); "tile_w" = 32 (2^20: 1024-thread workgroups, 256-byte segments);
- *   "small_reg" (n <= 32768: 1 = the shipped kernels; 3 = the direct-addressing 16-point kernels up to 4096; 2 = + the
- *   wavefront-shuffle exchange at 32 / 64 / 128; 0 = LDS radix-2 kernel up to 4096); "inject_launch_failure" (pipelined
- *   paths: the launch of that group fails once -- the error path of fwa_plan_exec under test). */
+ *   "wgs"; "device_error" (path 5; synchronises the device; non-zero = a bounded in-kernel spin timed out);
+ *   "small_reg" (n <= 32768: 1 = the shipped kernels; 3 = the direct-addressing 16-point kernels at 16 .. 4096; 2 = the
+ *   same up to 256 with the wavefront-shuffle (`__shfl_xor`) exchange at 32 / 64 / 128); "ring_rotate" (2^20: the groups
+ *   walk through a ring that many times larger); "inject_launch_failure" (pipelined paths: the launch of that group
+ *   fails once -- the error path of fwa_plan_exec under test).
+ * "tile_w" reads 16 (the only tile width of the 2^20 pipeline; it can be "set" to 16 only). */
 int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value);
 int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value);
 

@@ -1,14 +1,16 @@
 """GPU tests of the LABORATORY build (fft_wgpu_amd/libfft_wgpu_amd_lab.so, `make -C fft_wgpu_amd/csrc lab`): the kernel
 families that measured slower than the shipped ones and were moved out of the product library
--- persistent 2^20 ring (path 5), L2 teams (path 8), 1024-thread 2^20 tiles (tile_w = 32), the direct 16-point kernels,
-the wavefront-shuffle exchange and the LDS radix-2 kernel (small_reg = 3 / 2 / 0).  They stay correct and, where they share
-arithmetic with the shipped kernels, bit-identical to them; the product library rejects their keys.
+-- the persistent 2^20 ring (path 5: the number DESIGN.md section 4 cites), the direct 16-point kernels with the
+wavefront-shuffle exchange BASELINE.json's north_star names (small_reg = 3 / 2) -- and the two test knobs ring_rotate and
+inject_launch_failure.  They stay correct and, where they share arithmetic with the shipped kernels, bit-identical to them;
+the product library rejects their keys.  (Round 6 removed L2 teams, the 32-column 2^20 tile, the LDS radix-2 and n < 16
+kernels, whose only loaders were the tests of this file: profiles/round6/lab_pruned_families.patch.)
 """
 import numpy as np
 import pytest
 
 from conftest import REL_TOL  # noqa: F401
-from test_gpu_parity import (GEOMETRIES_32, _c2_n1m_body, _check, _fixture_sizes_body, _n1m_geometries_body, _run)
+from test_gpu_parity import _check, _fixture_sizes_body, _run
 
 pytestmark = pytest.mark.gpu
 
@@ -23,20 +25,23 @@ def gpu():
     return fw, dev, queue
 
 
-@pytest.mark.parametrize("small_reg", [2, 3, 0])
+@pytest.mark.parametrize("small_reg", [2, 3])
 def test_fixture_sizes_laboratory_kernels(gpu, oracle, k4, small_reg):
-    """the 16-point kernels at every size (small_reg = 3), + the wavefront-shuffle exchange at n = 32 / 64 / 128 (2), the
-    LDS radix-2 kernel (0): every fixture size, forward / unscaled inverse / inverse."""
+    """the 16-point kernels at 16 .. 4096 (small_reg = 3; the shipped kernels below and above), + the wavefront-shuffle
+    exchange at n = 32 / 64 / 128 (2): every fixture size, forward / unscaled inverse / inverse."""
     _fixture_sizes_body(gpu, oracle, k4, None, small_reg)
 
 
-@pytest.mark.parametrize("batch,group,streams,tile_w", [(4, 8, 2, 32), (5, 2, 1, 32), (17, 4, 3, 32), (23, 3, 2, 32)])
-def test_config_c2_n1m_tile_w32(gpu, oracle, batch, group, streams, tile_w):
-    _c2_n1m_body(gpu, oracle, batch, group, streams, tile_w)
-
-
-def test_n1m_tile_w32_geometries_are_bit_identical(gpu, oracle):
-    _n1m_geometries_body(gpu, oracle, GEOMETRIES_32)
+def test_small_reg_accepts_only_its_three_values(gpu):
+    fw, dev, queue = gpu
+    plan = fw.Forward(dev, queue, dev.create_buffer(8 * 64 * 4), 64)
+    for bad in (0, 4, -1):
+        with pytest.raises(fw.FwaError) as e:
+            plan.set("small_reg", bad)
+        assert e.value.status == 1
+    for ok in (3, 2, 1):
+        plan.set("small_reg", ok)
+        assert plan.get("small_reg") == ok
 
 
 def test_n1m_ring_rotate_is_bit_identical(gpu, oracle):
@@ -88,46 +93,6 @@ def test_n1m_persistent_ring_large_batch_bit_identical(gpu, oracle):
             assert plan.get("device_error") == 0
             bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
             assert bad.size == 0, (kw, rep, bad.size, bad[:8])
-
-
-@pytest.mark.parametrize("lg,batch,max_teams", [(16, 1, None), (16, 7, None), (16, 100, None), (16, 33, 2), (17, 5, None),
-                                                (17, 40, None), (17, 9, 1), (18, 3, None), (18, 21, None)])
-def test_team_pipeline_l2_resident(gpu, oracle, lg, batch, max_teams):
-    """path 8: both passes in ONE persistent launch, workgroups teamed up per XCD, the intermediate handed over through
-    that XCD's L2 with plain stores, sc1 loads and flag barriers.  Same tile arithmetic as the per-pass launches with the
-    same factorisation: results must be bit-identical (a stale line anywhere shows up as mismatching 128-byte lines), and
-    no bounded spin may have timed out.  Runs twice back to back on the same slabs."""
-    fw, dev, queue = gpu
-    n = 1 << lg
-    x = oracle.gen_input(n, batch, first_transform=lg)
-    f0 = lg // 2
-    ref, which_ref, _ = _run(fw, dev, queue, "Forward", x, n, factors=f0 | ((lg - f0) << 8), rows32=0, colsw=0)  # same tile arithmetic
-    _check(oracle, ref, oracle.dft_f64(x, n, -1), n)
-    for rep in range(2):
-        y, which, plan = _run(fw, dev, queue, "Forward", x, n, path=8, max_teams=max_teams)
-        assert plan.get("path") == 8 and plan.get("launches_per_exec") == 1 and which == which_ref == lg % 2
-        assert plan.get("device_error") == 0
-        bad = np.flatnonzero(y.view(np.uint64) != ref.view(np.uint64))
-        assert bad.size == 0, (lg, batch, rep, bad.size, bad[:8])
-    z, _, plan = _run(fw, dev, queue, "Inverse", ref, n, path=8, max_teams=max_teams)
-    assert plan.get("device_error") == 0
-    _check(oracle, z, x.astype(np.complex128), n)
-
-
-
-def test_team_rejects_grids_that_cannot_form_a_team(gpu, oracle):
-    """with fewer than 8 x team-size workgroups no XCD may fill a team and the launch would transform
-    nothing while reporting success -- the key is rejected instead."""
-    fw, dev, queue = gpu
-    n = 1 << 16
-    src = dev.create_buffer(n * 8 * 64)
-    plan = fw.Forward(dev, queue, src, n)
-    plan.set("path", 8)
-    team = plan.get("wgs") // (8 * plan.get("max_teams"))
-    with pytest.raises(fw.FwaError) as e:
-        plan.set("wgs", team)
-    assert e.value.status == 1
-    plan.set("wgs", 8 * team)
 
 
 @pytest.mark.parametrize("n,batch,group,streams,fail_at", [(1 << 20, 40, 4, 2, 7), (1 << 20, 40, 4, 2, 0), (1 << 18, 64, 8, 2, 5), (1 << 20, 12, 4, 1, 2)])

@@ -99,7 +99,7 @@ def test_reference_known_answers(gpu, known_answers):
 
 
 # ---- K4: numpy float64 fixtures, every power of two 2..1024: the shipped kernels (k_chunk up to 256, k_small32 from 512)
-# and the literal one-launch-per-stage recurrence (path=2); the laboratory kernels (small_reg = 0, 2, 3) run the same
+# and the literal one-launch-per-stage recurrence (path=2); the laboratory kernels (small_reg = 2, 3) run the same
 # body in tests/test_gpu_lab.py ----
 def _fixture_sizes_body(gpu, oracle, k4, path, small_reg):
     fw, dev, queue = gpu
@@ -206,8 +206,6 @@ GEOMETRIES_16 = (dict(tile_w=16), dict(tile_w=16, xcd_swizzle=0), dict(tile_w=16
                  # active when an XCD gets whole runs of 64 tiles (group 16, 8), plain mapping otherwise (group 7, 20)
                  dict(group=16, streams=1), dict(group=8, streams=1), dict(group=16, streams=2, xcd_swizzle=1),
                  dict(group=20, streams=1, xcd_swizzle=7), dict(group=16, streams=1, xcd_swizzle=1))
-GEOMETRIES_32 = (dict(tile_w=32), dict(tile_w=32, group=8, streams=2, xcd_swizzle=0), dict(tile_w=32, group=7, streams=1),
-                 dict(tile_w=32, group=32, streams=2))
 
 
 def _n1m_geometries_body(gpu, oracle, geometries):
@@ -819,21 +817,25 @@ def test_product_library_rejects_laboratory_settings(gpu):
     assert not dev.lab
     buf = dev.create_buffer(8 << 20 << 3)      # 2^20 x 8
     p = fw.Forward(dev, queue, buf, 1 << 20)
-    for key, val in (("path", 5), ("tile_w", 32), ("depth", 4), ("ring_slots", 6), ("wgs", 512), ("max_teams", 2)):
+    for key, val in (("path", 5), ("tile_w", 32), ("depth", 4), ("ring_slots", 6), ("wgs", 512), ("ring_rotate", 2),
+                     ("inject_launch_failure", 0)):
         with pytest.raises(fw.FwaError) as e:
             p.set(key, val)
         assert e.value.status == 6, (key, e.value.status)
+    with pytest.raises(fw.FwaError) as e:
+        p.set("max_teams", 2)                   # a key of the team path, which left the tree in round 6
+    assert e.value.status == 1
     assert p.get("path") == 1 and p.get("tile_w") == 16
     p.set("tile_w", 16)
     small = fw.Forward(dev, queue, dev.wrap_buffer(buf.device_ptr, 8 * 4096), 64)
-    for val in (0, 2, 3):
+    for val in (2, 3):
         with pytest.raises(fw.FwaError) as e:
             small.set("small_reg", val)
         assert e.value.status == 6
     small.set("small_reg", 1)
     mid = fw.Forward(dev, queue, dev.wrap_buffer(buf.device_ptr, 8 << 16 << 5), 1 << 16)
     with pytest.raises(fw.FwaError) as e:
-        mid.set("path", 8)
+        mid.set("path", 8)                      # no such path any more (it was the team path)
     assert e.value.status == 6 and mid.get("path") == 7
 
 
