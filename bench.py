@@ -453,13 +453,22 @@ def main():
         achieved = ALGO_BYTES_PER_SAMPLE * n * batch / (slow_ms * 1e-3) / 1e9
         # Figures that cannot be measured inside the timed run (PMC counters need their own rocprofv3 passes; the
         # linear-stream floors are probe programs): read from profiles/bench_reference.json, each with its source.
-        traffic = traffic_source = floors = isolated = None
+        traffic = traffic_source = floors = isolated = taken_on = None
+        traffic_stale = None
         tpath = os.path.join(ROOT, "profiles", "bench_reference.json")
         if os.path.exists(tpath):
             try:
                 ref = json.load(open(tpath))
                 traffic = ref.get("traffic_bytes_per_exec", {}).get(f"{n}x{batch}")
                 traffic_source = ref.get("traffic_source") if traffic else None
+                # the stored figure belongs to the kernel sources it was profiled on: say so when they have changed since
+                taken_on = ref.get("taken_on") if traffic else None
+                if traffic:
+                    import hashlib
+                    h = hashlib.sha256()
+                    for rel in (taken_on or {}).get("kernel_sources", ["fft_wgpu_amd/csrc/tile_1m.h", "fft_wgpu_amd/csrc/kernels_1m.hip"]):
+                        h.update(open(os.path.join(ROOT, rel), "rb").read())
+                    traffic_stale = (taken_on or {}).get("kernel_source_sha256") != h.hexdigest()
                 if n == (1 << 20):
                     floors = ref.get("measured_floors")
                     isolated = ref.get("isolated_kernel_us")
@@ -493,6 +502,7 @@ def main():
             "per_rank_hip_event_ms": per_rank_ev_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "rank": slow, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_stale": traffic_stale, "traffic_taken_on": taken_on,
                          "measured_floors": floors, "isolated_kernel_us": isolated,
                          "kernel": "k_p1_1m + k_p2_1m (the launches of one fwa_plan_exec: pass 1 then pass 2 per group "
                                    "of transforms, alternating over the chains)",

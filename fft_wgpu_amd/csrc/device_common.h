@@ -2,7 +2,7 @@
 #pragma once
 #include "kernels.h"
 
-// Diagnostic hooks: empty in the library.  tools/phase_probe.hip defines them before including a kernel source to
+// Diagnostic hooks: empty in the library.  tools/archive/phase_probe.hip defines them before including a kernel source to
 // record in-kernel time stamps (cdna_hip_programming.md section 7, "In-kernel stamps": a separate diagnostic build, the
 // stamps go to a buffer of their own).
 #ifndef FWA_STAMP

@@ -16,13 +16,13 @@ namespace fwa {
 // 128 KiB; measured 0.37 / 0.40 -> 0.63 / 0.66 of the roofline).  Same Stockham recurrence per stage, radix R: idx = s*J + j, inputs idx + m*n/R, output q at
 // s*R*J + j + q*J times W_n^{s*J*q}.  Positions are padded by one float per 32 (conflict-free b32 accesses).
 // ---------------------------------------------------------------------------
-// The body for workgroup index `blk` (k_small32: blk = blockIdx.x; tools/small32_persist_probe.hip walks it through a
+// The body for workgroup index `blk` (k_small32: blk = blockIdx.x; tools/archive/small32_persist_probe.hip walks it through a
 // persistent loop, measured no faster: profiles/round3/probe_small32_persistent_negative.txt).
 // PREFETCH: where the twiddle-table look-ups are issued.  At the point of use (0) each costs its wave an exposed cache
 // latency between the last data load landing and the exchange; they depend on the thread index only, so they can go out
 // BEFORE the data loads (bit 0: the twiddles of stage 0, bit 1: those of stage 1 of the three-stage sizes) or right BEHIND
 // them, before the wait for the data (bits 2, 3).  Per size, at the 32-GiB footprint, interleaved, bit-identical results
-// (tools/small32_prefetch_probe.hip).  With the plain block -> chunk map (profiles/round5/probe_small32_twiddle_prefetch.jsonl):
+// (tools/archive/small32_prefetch_probe.hip).  With the plain block -> chunk map (profiles/round5/probe_small32_twiddle_prefetch.jsonl):
 // 2^10 0.775 -> 0.790, 2^11 0.740 -> 0.790, 2^12 0.705 -> 0.738, 2^13 0.717 -> 0.739.  With the pair map of one_launch_block
 // (device_common.h), which came later and lifts the point-of-use form by more (probe_small32_twiddle_prefetch_pair_map.jsonl):
 // 2^10 0.807 -> 0.814 (behind), 2^11 0.806 -> 0.807 (both stages, before), 2^12 0.774 -> 0.778 (behind) -- kept -- and 2^13

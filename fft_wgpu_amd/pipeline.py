@@ -4,7 +4,7 @@ A: upload + transform + device copy, B: read-back -- so the read-back of iterati
 (the host link is full duplex).  Host-link bound by design: this is the PCIe-inclusive figure DESIGN.md quotes next
 to (never instead of) the device-resident throughput.
 
-Structure, chosen by measurement (tools/pipe_probe.py, profiles/round2/host_pipeline_probe.jsonl; N = 512 x 2500 =
+Structure, chosen by measurement (tools/archive/pipe_probe.py, profiles/round2/host_pipeline_probe.jsonl; N = 512 x 2500 =
 10.24 MB each way per iteration; the link alone carries 53 GB/s one way, 47 GB/s each way with both directions busy):
   * one device-side dependency per iteration (A -> B, an event recorded after the device copy): 0.23 ms / iteration;
   * guarding slot reuse with a second device-side dependency (B -> A) costs 2x on this stack (0.46 ms): the runtime

@@ -13,7 +13,7 @@ import subprocess
 from conftest import ROOT
 
 DOCS = ["DESIGN.md", "HISTORY.md", "BASELINE.md", "README.md", "INTEGRATION.md", "profiles/round3/README.md", "profiles/round4/README.md", "profiles/round5/README.md",
-        "tools/README.md"]
+        "tools/README.md", "tools/archive/README.md"]
 DATA_EXT = r"(?:jsonl|json|txt|csv|patch|npz)"
 
 

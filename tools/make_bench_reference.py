@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""tools/make_bench_reference.py DIR ROUND -- refresh profiles/bench_reference.json from the summaries of ONE profile job
+"""tools/make_bench_reference.py DIR ROUND [COMMIT] -- refresh profiles/bench_reference.json from the summaries of ONE profile job
 (tools/run_round_profiles.sh writes them to DIR just before it takes the bench line, so that the line, the PMC summaries and
-the kernel statistics of a round are one consistent set: VERDICT round 4, item 5).
+the kernel statistics of a round are one consistent set: VERDICT round 4, item 5).  The file is stamped with the commit the job
+ran on (COMMIT, or $FWA_COMMIT: the GPU box has no .git) and with sha256(csrc/tile_1m.h + csrc/kernels_1m.hip), the sources of
+the two kernels the traffic figure belongs to: bench.py marks the figure `"traffic_stale": true` when that hash has moved on.
 
 Reads DIR/a_pmc_fetch_summary.txt, a_pmc_write_summary.txt (tools/pmc_summary.py) and a_trace_streams1_summary.txt
 (tools/trace_summary.py); keeps the probe-derived entries (measured_floors) of the existing file.
@@ -12,6 +14,15 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("fft_wgpu_amd/csrc/tile_1m.h", "fft_wgpu_amd/csrc/kernels_1m.hip")   # bench.py hashes the same list
+
+
+def kernel_source_sha256(root=ROOT):
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(root, rel), "rb").read())
+    return h.hexdigest()
 
 
 def per_dispatch(path, kernel):
@@ -30,6 +41,11 @@ def mean_us(path, kernel):
 
 def main():
     d, rnd = sys.argv[1], sys.argv[2]
+    commit = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("FWA_COMMIT", "")
+    if not commit:
+        import subprocess
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True)
+        commit = r.stdout.strip() if r.returncode == 0 else "unknown (no .git on this box and no FWA_COMMIT given)"
     ref_path = os.path.join(ROOT, "profiles", "bench_reference.json")
     ref = json.load(open(ref_path))
     f1, n1 = per_dispatch(os.path.join(d, "a_pmc_fetch_summary.txt"), "k_p1_1m")
@@ -62,6 +78,8 @@ def main():
         "source": f"profiles/round{rnd}/a_kernel_stats_streams1_isolated.csv / a_trace_streams1_summary.txt (bench.py --streams 1: one "
                   f"chain, no second launch in flight; {c1} launches each); with two chains the same launches take {t1:.1f} / {t2:.1f} us "
                   f"each while two are in flight (a_trace_default_summary.txt)"}
+    ref["taken_on"] = {"commit": commit, "round": int(rnd), "kernel_sources": list(KERNEL_SOURCES),
+                       "kernel_source_sha256": kernel_source_sha256()}
     ref["_comment"] = ("Figures bench.py cannot measure inside its timed run, each with its source; refreshed by "
                        "tools/make_bench_reference.py inside the round's profile job, before the bench line is taken.")
     json.dump(ref, open(ref_path, "w"), indent=1)

@@ -20,7 +20,7 @@ python3 tools/trace_summary.py $O/prof_streams1 > $O/a_trace_streams1_summary.tx
 cp "$(find $O/prof_default -name '*kernel_stats.csv' | head -1)" $O/a_kernel_stats_default.csv
 cp "$(find $O/prof_streams1 -name '*kernel_stats.csv' | head -1)" $O/a_kernel_stats_streams1_isolated.csv
 rm -rf $O/prof_default $O/prof_streams1 $O/pmc_fetch $O/pmc_write
-python3 tools/make_bench_reference.py $O $R > $O/bench_reference.log 2>&1
+python3 tools/make_bench_reference.py $O $R "${FWA_COMMIT:-}" > $O/bench_reference.log 2>&1   # FWA_COMMIT=$(git rev-parse --short=12 HEAD) in the gpurun command line: the box has no .git
 cp profiles/bench_reference.json $O/bench_reference.json
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/a_bench_default.json 2> $O/bench_default.err
 echo "profiles done"
