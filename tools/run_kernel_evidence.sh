@@ -17,7 +17,7 @@ run() {  # lg | norm
   echo "== $kind n = 2^$lg x $b: 3 execs; algorithmic bytes per exec 34359738.4 KB read + as much written" >> $O
   rm -rf gpurun_out/ke
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ke -- python3 tools/one_exec.py --lg $lg --batch $b --execs 3 --kind $kind > gpurun_out/ke.log 2>&1
-  grep one_exec gpurun_out/ke.log >> $O
+  grep '^{"one_exec"' gpurun_out/ke.log >> $O
   python3 tools/trace_summary.py gpurun_out/ke | grep -v "k_fill\|k_spin\|rocclr" >> $O
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/ke

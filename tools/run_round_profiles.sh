@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/run_round_profiles.sh ROUND -- the measurement set behind profiles/roundN/a_* and b_* (run on the GPU box through
+# tools/run_round_profiles.sh ROUND [profiles-only] -- the measurement set behind profiles/roundN/a_* and b_* (run on the GPU box through
 # gpurun; results land in gpurun_out/roundN/, copy what is to be judged into profiles/roundN/).
 # Order: PMC passes and kernel statistics FIRST, then profiles/bench_reference.json is refreshed
 # from them, and only then the bench line is taken -- so that the line and the summaries of one job agree.
@@ -8,7 +8,9 @@ R=${1:?round number}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round$R
 mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --spread 0"
+# the profiled runs leave out the legs that launch the calibration kernels at other sizes (spread, batch-1 configurations): the
+# per-dispatch means of k_copy / k_scale / k_small32<10> then are the 8 / 16 / 32-GiB passes the FETCH x 2 rule is checked on
+B="python3 bench.py --no-cpu-baseline --spread 0 --config-execs 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- $B --steps 5 --warmup 2 > $O/prof_default.log 2>&1
@@ -24,6 +26,7 @@ python3 tools/make_bench_reference.py $O $R "${FWA_COMMIT:-}" > $O/bench_referen
 cp profiles/bench_reference.json $O/bench_reference.json
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/a_bench_default.json 2> $O/bench_default.err
 echo "profiles done"
+if [ "${2:-}" = profiles-only ]; then exit 0; fi
 timeout -k 10 400 python3 tools/size_bench.py --lg-max 24 > $O/b_size_sweep_2GiB.jsonl 2>&1
 timeout -k 10 400 python3 tools/size_bench.py --lg-min 1 --lg-max 24 --total-lg 32 --no-latency-shapes > $O/b_size_sweep_32GiB.jsonl 2>&1
 echo "sweeps done"
