@@ -99,7 +99,7 @@ hipError_t setup_lab_1m_kernels();
 size_t fused_c2_ctl_bytes();
 hipError_t launch_fused_c2(int dir, const v2f *in, v2f *slab, v2f *out, const v2f *tw_a, const v2f *tw_b, const v2f *tw_c,
                            const v2f *lo1, const v2f *hi1, const v2f *lo_b, const v2f *hi_b, uint32_t *ctl, float scale,
-                           hipStream_t st);
+                           bool stamps, hipStream_t st);
 #endif
 
 }  // namespace fwa

@@ -47,6 +47,7 @@ struct FusedArgs {
     const v2f *tw_a, *tw_b, *tw_c, *lo1, *hi1, *lo_b, *hi_b;
     uint32_t *ctl;
     float scale;
+    uint32_t stamps;   // diagnostic: 1 = every workgroup records six s_memrealtime stamps (100 MHz) behind the flags
 };
 
 template <int DIR>
@@ -58,33 +59,43 @@ __global__ __launch_bounds__(256) void k_fused_c2(FusedArgs a)
     const uint32_t v = __builtin_amdgcn_readfirstlane(
         __hip_atomic_load(a.ctl + FUSED_FLAG_WORD + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     v2f *lds_w = reinterpret_cast<v2f *>(smem) + wave * (16 * tile_pstr(64));
+    uint64_t *stamp = reinterpret_cast<uint64_t *>(a.ctl + FUSED_FLAG_WORD + FUSED_WGS) + wg * 8;
+    auto mark = [&](int slot) {
+        if (a.stamps && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[slot] = __builtin_amdgcn_s_memrealtime(); }
+    };
+    mark(0);
     const uint32_t bid = wg * 4 + wave;   // passes A and B: one 64-point x 16-column tile per wave
     {   // pass A: FFT over n1 (pitch N / N1), four-step twiddle of domain n, user buffer -> slab
         tile_body<6, 16, DIR, TILE_COLS, true, AUX_NT, AUX_SC1>(a.in + bid * 16, a.slab + bid * 16, bid * 16, a.tw_a, a.lo1, a.hi1,
                                                                  N / N1, 0, 1.0f, lds_w, lane);
     }
+    mark(1);
     grid_barrier_256(a.ctl, wg, v + 1, tid);
+    mark(2);
     {   // pass B: FFT over n2 inside every k1-plane (pitch N3), twiddle of domain N2 * N3, in place in the slab
         const uint32_t tile = bid % (N3 / 16), d1 = bid / (N3 / 16);
         v2f *p = a.slab + d1 * (N2 * N3) + tile * 16;
         tile_body<6, 16, DIR, TILE_COLS, true, AUX_SC1, AUX_SC1>(p, p, tile * 16, a.tw_b, a.lo_b, a.hi_b, N3, 0, 1.0f, lds_w, lane);
     }
+    mark(3);
     grid_barrier_256(a.ctl, wg, v + 2, tid);
+    mark(4);
     {   // pass C: 256-point rows of the last axis, 16 adjacent k1 per workgroup, transposed store into the result buffer
         const uint32_t tile = wg % (N1 / 16), d1 = wg / (N1 / 16);
         tile_body<8, 16, DIR, TILE_ROWS_T, true, AUX_SC1, AUX_NT>(a.slab + d1 * N3 + tile * (16 * (N / N1)), a.out + d1 * N1 + tile * 16,
                                                                    tile * 16, a.tw_c, nullptr, nullptr, N / N1, N1 * N2, a.scale,
                                                                    reinterpret_cast<v2f *>(smem), tid);
     }
+    mark(5);
 }
 
-size_t fused_c2_ctl_bytes() { return (FUSED_FLAG_WORD + FUSED_WGS) * sizeof(uint32_t); }
+size_t fused_c2_ctl_bytes() { return (FUSED_FLAG_WORD + FUSED_WGS) * sizeof(uint32_t) + FUSED_WGS * 8 * sizeof(uint64_t); }
 
 hipError_t launch_fused_c2(int dir, const v2f *in, v2f *slab, v2f *out, const v2f *tw_a, const v2f *tw_b, const v2f *tw_c,
                            const v2f *lo1, const v2f *hi1, const v2f *lo_b, const v2f *hi_b, uint32_t *ctl, float scale,
-                           hipStream_t st)
+                           bool stamps, hipStream_t st)
 {
-    FusedArgs a{in, slab, out, tw_a, tw_b, tw_c, lo1, hi1, lo_b, hi_b, ctl, scale};
+    FusedArgs a{in, slab, out, tw_a, tw_b, tw_c, lo1, hi1, lo_b, hi_b, ctl, scale, stamps ? 1u : 0u};
     const size_t lds_ab = 4 * tile_lds(6, 16), lds_c = tile_lds(8, 16);
     const size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
     void *args[] = {&a};

@@ -588,7 +588,7 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
 #ifdef FWA_LAB
             if (plan->fused) {   // laboratory: the three passes of C2 in one launch
                 e = fwa::launch_fused_c2(dir, a, plan->ring, out, tb.tw_l[0], tb.tw_l[1], tb.tw_l[2], tb.tw_lo1, tb.tw_hi1,
-                                         tb.tw_lo_b, tb.tw_hi_b, plan->ring_ctl, scale, st);
+                                         tb.tw_lo_b, tb.tw_hi_b, plan->ring_ctl, scale, plan->fused == 2, st);
                 plan->last_stream = st;
                 plan->ran_on_stream = true;
                 break;

@@ -46,6 +46,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
     }
     else if (k == "small_reg") *value = plan->small_reg;
     else if (k == "fused") *value = plan->fused;
+    else if (k == "ctl_ptr") *value = (int64_t)reinterpret_cast<uintptr_t>(plan->ring_ctl);   // laboratory diagnostics
     else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "rows32") *value = plan->rows32;
     else if (k == "colsw") *value = plan->colsw;
@@ -168,7 +169,7 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         // laboratory: one 2^20 transform (config C2) in ONE launch, two in-kernel grid barriers (kernels_lab_fused.hip)
         if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "fused is a laboratory form (libfft_wgpu_amd_lab.so)");
 #ifdef FWA_LAB
-        if (value != 0 && value != 1) return fail(ctx, FWA_ERR_INVALID_ARG, "fused is 0 or 1");
+        if (value < 0 || value > 2) return fail(ctx, FWA_ERR_INVALID_ARG, "fused is 0, 1 or 2 (2: with in-kernel time stamps)");
         if (plan->path != PATH_TILED || plan->lg != 20 || plan->batch != 1 || plan->lf[0] != 6 || plan->lf[1] != 6 || plan->lf[2] != 8)
             return fail(ctx, FWA_ERR_UNSUPPORTED, "fused applies to one 2^20 transform with factors 64 x 64 x 256");
         if (ctx->prop.multiProcessorCount < 256)
