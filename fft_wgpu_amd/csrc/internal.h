@@ -155,8 +155,6 @@ struct fwa_plan {
     int64_t depth = 8;             // pass-2 tiles of transform t run beside pass-1 tiles of transform t + depth
     int64_t ring_slots = 12;       // transforms of intermediate kept (>= depth + 1)
     int64_t wgs = 512;             // persistent workgroups (2 per CU)
-    // laboratory: config C2's three passes as ONE launch with in-kernel grid barriers (kernels_lab_fused.hip)
-    int64_t fused = 0;
     // laboratory: the launch of this group fails once (error path of run_groups under test)
     int64_t inject_fail_group = -1;
 };

@@ -94,12 +94,6 @@ hipError_t launch_ring_1m(int dir, const v2f *src, v2f *dst, v2f *ring, const v2
                           uint32_t *ctl, uint32_t batch, uint32_t depth, uint32_t ring_slots, uint32_t n_workgroups,
                           float scale, hipStream_t st);
 hipError_t setup_lab_1m_kernels();
-// config C2 (one 2^20 transform, factors 64 x 64 x 256) as ONE launch with two in-kernel grid barriers (kernels_lab_fused.hip);
-// ctl = fused_c2_ctl_bytes() bytes, zeroed once when the plan is switched to this form; ctl[1] != 0 = a bounded spin timed out
-size_t fused_c2_ctl_bytes();
-hipError_t launch_fused_c2(int dir, const v2f *in, v2f *slab, v2f *out, const v2f *tw_a, const v2f *tw_b, const v2f *tw_c,
-                           const v2f *lo1, const v2f *hi1, const v2f *lo_b, const v2f *hi_b, uint32_t *ctl, float scale,
-                           bool stamps, hipStream_t st);
 #endif
 
 }  // namespace fwa

@@ -156,7 +156,6 @@ int32_t setup_path(fwa_plan *p)
 size_t ctl_bytes(const fwa_plan *p)
 {
 #ifdef FWA_LAB
-    if (p->fused) return fwa::fused_c2_ctl_bytes();
     return fwa::ring_ctl_bytes(p->batch);
 #else
     (void)p;
@@ -585,15 +584,6 @@ int32_t fwa_plan_exec(fwa_plan *plan, fwa_stream *stream, fwa_buf **result)
             // result buffer (src for even log2 n -- in place at group granularity -- else second).  The three passes are
             // built once per exec (TiledPass above: kernel choice + launch arguments, nothing on the heap) and only
             // receive the group's pointers here.
-#ifdef FWA_LAB
-            if (plan->fused) {   // laboratory: the three passes of C2 in one launch
-                e = fwa::launch_fused_c2(dir, a, plan->ring, out, tb.tw_l[0], tb.tw_l[1], tb.tw_l[2], tb.tw_lo1, tb.tw_hi1,
-                                         tb.tw_lo_b, tb.tw_hi_b, plan->ring_ctl, scale, plan->fused == 2, st);
-                plan->last_stream = st;
-                plan->ran_on_stream = true;
-                break;
-            }
-#endif
             const TiledShape shape = tiled_shape(plan);
             const TiledPass pa = pass_a(plan, shape, tb, dir), pb = pass_b(plan, shape, tb, dir),
                             pc = pass_c(plan, shape, tb, dir, scale);

@@ -45,8 +45,6 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         }
     }
     else if (k == "small_reg") *value = plan->small_reg;
-    else if (k == "fused") *value = plan->fused;
-    else if (k == "ctl_ptr") *value = (int64_t)reinterpret_cast<uintptr_t>(plan->ring_ctl);   // laboratory diagnostics
     else if (k == "p1_gen") *value = plan->p1_gen;
     else if (k == "rows32") *value = plan->rows32;
     else if (k == "colsw") *value = plan->colsw;
@@ -62,7 +60,7 @@ int32_t fwa_plan_get_i64(const fwa_plan *plan, const char *key, int64_t *value)
         switch (plan->path) {
             case PATH_TWOPASS_1M: *value = 2 * ng; break;
             case PATH_RING_1M: *value = 1; break;
-            case PATH_TILED: *value = plan->fused ? 1 : (plan->lf[2] ? 3 : 2) * ng; break;
+            case PATH_TILED: *value = (plan->lf[2] ? 3 : 2) * ng; break;
             case PATH_R2_GLOBAL: *value = plan->lg; break;
             case PATH_IDENTITY: *value = (plan->kind == FWA_INVERSE_SCALED) ? 1 : 0; break;
             default: *value = 1;
@@ -163,23 +161,6 @@ int32_t fwa_plan_set_i64(fwa_plan *plan, const char *key, int64_t value)
         int64_t &flag = k == "p1_gen" ? plan->p1_gen : k == "rows32" ? plan->rows32
                         : k == "colsw" ? plan->colsw : plan->tile_ring;
         flag = value != 0;
-        return FWA_OK;
-    }
-    if (k == "fused") {
-        // laboratory: one 2^20 transform (config C2) in ONE launch, two in-kernel grid barriers (kernels_lab_fused.hip)
-        if (!kLab) return fail(ctx, FWA_ERR_UNSUPPORTED, "fused is a laboratory form (libfft_wgpu_amd_lab.so)");
-#ifdef FWA_LAB
-        if (value < 0 || value > 2) return fail(ctx, FWA_ERR_INVALID_ARG, "fused is 0, 1 or 2 (2: with in-kernel time stamps)");
-        if (plan->path != PATH_TILED || plan->lg != 20 || plan->batch != 1 || plan->lf[0] != 6 || plan->lf[1] != 6 || plan->lf[2] != 8)
-            return fail(ctx, FWA_ERR_UNSUPPORTED, "fused applies to one 2^20 transform with factors 64 x 64 x 256");
-        if (ctx->prop.multiProcessorCount < 256)
-            return fail(ctx, FWA_ERR_UNSUPPORTED, "fused needs 256 compute units (all its workgroups resident)");
-        if (value && !plan->ring_ctl) {
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&plan->ring_ctl), fwa::fused_c2_ctl_bytes()));
-            HIP_TRY(ctx, hipMemset(plan->ring_ctl, 0, fwa::fused_c2_ctl_bytes()));
-        }
-        plan->fused = value;
-#endif
         return FWA_OK;
     }
     if (k == "small_reg") {

@@ -11,7 +11,7 @@ from .device import Buffer
 # Tuning keys of fwa_plan_set_i64 in the order they must be applied ("factors" re-plans the pipeline, so it comes
 # before "group" / "streams").  No key changes what a plan computes.
 PLAN_KEYS = ("path", "factors", "group", "streams", "tile_w", "xcd_swizzle", "depth", "ring_slots", "wgs",
-             "small_reg", "fused", "p1_gen", "rows32", "colsw", "tile_ring", "ring_rotate", "inject_launch_failure")
+             "small_reg", "p1_gen", "rows32", "colsw", "tile_ring", "ring_rotate", "inject_launch_failure")
 
 
 class _Plan:
