@@ -6,7 +6,7 @@ process on ONE device with the variants interleaved round-robin (cdna_hip_progra
 A setting is "key=value,key=value" over the plan's tunables (group, streams, tile_w, cw, factors); factors may be
 written as 9.9 or 6.6.6.  One JSON line per setting.
 
-  python tools/sweep.py --lg 20 --batch 4096 --set "tile_w=16" --set "tile_w=32" --set "tile_w=32,group=8"
+  python tools/sweep.py --lg 20 --batch 4096 --set "group=16" --set "group=8,streams=4" --set "xcd_swizzle=1"
 """
 import argparse
 import json
@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--set", action="append", default=[], help="one plan setting (repeatable); '' = defaults")
     ap.add_argument("--copy", action="store_true", help="float4 copy rate vs footprint first")
-    ap.add_argument("--lab", action="store_true", help="load the laboratory build (paths 5 / 8, tile_w = 32, small_reg != 1)")
+    ap.add_argument("--lab", action="store_true", help="load the laboratory build (path 5, small_reg = 2 / 3, ring_rotate)")
     args = ap.parse_args()
     dev, queue = fw.prepare_gpu(0, lab=args.lab)
     n = 1 << args.lg
